@@ -1,0 +1,205 @@
+/*
+ * sfm_ba.h - C ABI of libsfm_ba.so, the MI355X (gfx950) bundle-adjustment library.
+ *
+ * Every entry point takes plain pointers and sizes.  Pointers named d_* are DEVICE
+ * pointers (HBM of the current HIP device); pointers named h_* are host pointers.
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).  All
+ * floating point data is IEEE fp64, all indices are int32.  Functions return
+ * SFM_BA_OK (0) or a negative SFM_BA_E* code; sfm_ba_error_string() names it.
+ * Kernels are enqueued on `stream` and the call returns without synchronising
+ * unless stated otherwise.
+ *
+ * The reference is pure Python (numpy); there is no FFI in it to bind.  Each entry
+ * point below states the reference function(s) whose work it performs, with paths
+ * relative to the reference checkout.
+ */
+#ifndef SFM_BA_H
+#define SFM_BA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFM_BA_VERSION 1
+
+/* status codes */
+#define SFM_BA_OK 0
+#define SFM_BA_EINVAL -1        /* bad argument (null pointer, negative size, bad stride) */
+#define SFM_BA_EHIP -2          /* a HIP runtime call failed; see sfm_ba_last_hip_error() */
+#define SFM_BA_ENONUNIQUE -3    /* "Found non-unique (i, j) pair"         src/sparse_ba.py:61-62 */
+#define SFM_BA_EMISSING_POINT -4 /* point ids not contiguous 0..max        src/sparse_ba.py:89 */
+#define SFM_BA_EMISSING_VIEW -5 /* viewpoint ids not contiguous 0..max    src/sparse_ba.py:91 */
+#define SFM_BA_ENOTPD -6        /* reduced camera system not positive definite (numpy raises LinAlgError
+                                   for a singular S at src/sparse_ba.py:275) */
+#define SFM_BA_ETOOBIG -7       /* a point is observed by more cameras than SFM_BA_MAX_VIEWS */
+
+/* doubles per prepared camera record (see sfm_ba_camera_prepare) */
+#define SFM_BA_CAM_BLK 56
+/* doubles per per-camera reduction record: 28 (upper triangle of U) + 7 (eps_a) + 7 (sum Y eps_b) + 1 (sum |eps|^2) */
+#define SFM_BA_CAM_RED 43
+/* largest number of observations of one point */
+#define SFM_BA_MAX_VIEWS 256
+
+/* flag bits written by sfm_ba_camera_prepare / sfm_ba_update_cameras into d_flags[camera] */
+#define SFM_BA_FLAG_DET_NOT_ONE 1   /* |det R - 1| > 1e-8 + 1e-5   src/utils.py:74-76 */
+#define SFM_BA_FLAG_ZERO_QUAT 2     /* |Q + dQ| ~ 0                src/bundle_adjustment.py:89-91 */
+#define SFM_BA_FLAG_NONFINITE 4     /* a NaN/Inf reached the camera record */
+
+int sfm_ba_version(void);
+const char* sfm_ba_error_string(int code);
+/* text of the last failing HIP call on the calling thread ("" if none) */
+const char* sfm_ba_last_hip_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Visibility plan.  Performs the work of `Indices.__init__` (src/sparse_ba.py:58-97): checks
+ * that (point, viewpoint) pairs are unique and that ids are contiguous, and builds the index
+ * structures the kernels walk: observations grouped by point, per-camera work items, and for
+ * every camera pair (j <= k) that shares a point the list of (obs of j, obs of k) pairs -
+ * the information `Indices.shared_point_indices` (src/sparse_ba.py:107-128) recomputes from a
+ * dense mask on every call.  Built on the host from host index arrays, then uploaded.
+ *   h_cam_idx, h_pt_idx : n_obs entries, any order (the reference emits frame-major order,
+ *                         src/bundle_adjustment.py:44-67)
+ *   n_cams_hint, n_pts_hint : 0 to derive max+1 as the reference does; a rank of a sharded
+ *                         run passes the global camera count (cameras it does not observe
+ *                         are then allowed) and its local point count
+ *   check              : non-zero to run the uniqueness / contiguity checks
+ * On success *out_plan receives an opaque handle; free it with sfm_ba_plan_destroy.
+ * Synchronous (blocks until the upload finished).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct sfm_ba_plan sfm_ba_plan;
+
+int sfm_ba_plan_create(const int32_t* h_cam_idx, const int32_t* h_pt_idx, int64_t n_obs,
+                       int32_t n_cams_hint, int32_t n_pts_hint, int check, sfm_ba_plan** out_plan);
+void sfm_ba_plan_destroy(sfm_ba_plan* plan);
+/* sizes: what[0]=n_cams, [1]=n_pts, [2]=n_obs, [3]=number of camera-pair blocks (j<=k) with a shared
+ * point, [4]=number of (obs,obs) pair entries, [5]=number of per-point pair slots (doubles/4 of d_T),
+ * [6]=number of per-camera work items, [7]=bytes of device memory held by the plan */
+int sfm_ba_plan_sizes(const sfm_ba_plan* plan, int64_t what[8]);
+/* bytes of the scratch workspace the assemble / back-substitution entry points need */
+int64_t sfm_ba_plan_workspace_bytes(const sfm_ba_plan* plan);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-camera records.  Work of `rotation_matrix_to_quaternion` (src/utils.py:62-105, four
+ * branches, quaternion order [x,y,z,w]), `compute_dR_dQ_mat` (src/jacobian.py:171-203, signs as
+ * written there) and the mixed rows fx*R0+ox*R2, fy*R1+oy*R2, R2 that every Jacobian function
+ * recomputes per observation (src/jacobian.py:29-49).
+ *   d_R [m,9] row-major rotations; d_C [m,3] centres; d_K [m,9] or [1,9] row-major intrinsics
+ *   (k_stride = 9 or 0; the Jacobians read fx=K[0], fy=K[4], ox=K[2], oy=K[5] only, as
+ *   src/jacobian.py:22-25 does); d_cam_blk [m, SFM_BA_CAM_BLK] out:
+ *     [0..8] mixed rows, [9..11] C, [12..47] dR/dQ (9x4 row-major), [48..51] Q, [52..55] fx,fy,ox,oy
+ *   d_flags [m] int32 out (OR-ed): SFM_BA_FLAG_DET_NOT_ONE where the reference would assert.
+ * ---------------------------------------------------------------------------------------- */
+int sfm_ba_camera_prepare(const double* d_R, const double* d_C, const double* d_K, int k_stride,
+                          int32_t m, double* d_cam_blk, int32_t* d_flags, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-observation Jacobian blocks and predictions.  Work of `compute_A_B`
+ * (src/bundle_adjustment.py:22-41) = `compute_pose_jacobian_mat` + `compute_X_jacobian_mat`
+ * (src/jacobian.py:215-220, :75-126) per observation, and of the projection inside
+ * `get_indices` (src/bundle_adjustment.py:55, src/utils.py:8-11).
+ *   d_P [m,12] projection matrices K[R|T] (may be NULL when d_x_pred is NULL)
+ *   d_X [n,3] points; d_cam_idx, d_pt_idx [N]
+ *   d_A [N,2,7] = [dF/dQ | dF/dC], d_B [N,2,3] = dF/dX  (either may be NULL to skip)
+ *   d_x_pred [N,2] (may be NULL)
+ * ---------------------------------------------------------------------------------------- */
+int sfm_ba_jacobian(const double* d_cam_blk, const double* d_P, const double* d_X,
+                    const int32_t* d_cam_idx, const int32_t* d_pt_idx, int64_t n_obs,
+                    double* d_A, double* d_B, double* d_x_pred, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Schur assembly.  Work of calc_U, calc_V_inv, calc_W, calc_Y, calc_S, calc_epsilon,
+ * calc_epsilon_a, calc_epsilon_b and calc_e (src/sparse_ba.py:147-271) as called by
+ * `SBA.compute` (src/sparse_ba.py:393-402).
+ *   d_A [N,2,7], d_B [N,2,3], d_x_true [N,2], d_x_pred [N,2] in the observation order the plan
+ *   was built from; d_weights [N,2,2] symmetric or NULL (identity, src/sparse_ba.py:387-388)
+ *   mu     : damping added to every V_i (src/sparse_ba.py:206,210)
+ *   mu_u   : damping added to every U_j (src/sparse_ba.py:194,197); a rank of a sharded run
+ *            passes 0 and adds mu after the all-reduce (sfm_ba_add_diagonal)
+ * Outputs:
+ *   d_S   [(7m+1), 7m] row-major: rows 0..7m-1 = S (both triangles; blocks of camera pairs
+ *         without a shared point are left untouched - zero the buffer once before the first call),
+ *         row 7m = e flattened
+ *   d_e [m,7], d_U [m,7,7], d_eps_a [m,7]      (d_U, d_eps_a may be NULL)
+ *   d_V_inv [n,3,3], d_eps_b [n,3]
+ *   d_cam_red [m, SFM_BA_CAM_RED] per-camera sums without damping (may be NULL): what a sharded
+ *         run all-reduces; [42] is the camera's sum of squared residuals
+ *   d_workspace : sfm_ba_plan_workspace_bytes(plan) bytes; holds per-observation and per-pair
+ *         intermediates that sfm_ba_back_substitute reads again
+ * V_i is inverted in closed form; the reference uses numpy.linalg.pinv, identical for the
+ * full-rank, well-conditioned V_i that any mu > 0 produces.
+ * ---------------------------------------------------------------------------------------- */
+int sfm_ba_schur_assemble(const sfm_ba_plan* plan, const double* d_A, const double* d_B,
+                          const double* d_x_true, const double* d_x_pred, const double* d_weights,
+                          double mu, double mu_u, double* d_S, double* d_e, double* d_U,
+                          double* d_eps_a, double* d_V_inv, double* d_eps_b, double* d_cam_red,
+                          void* d_workspace, void* stream);
+
+/* W [N,7,3] and Y [N,7,3] as the reference materialises them (calc_W, calc_Y,
+ * src/sparse_ba.py:215-234).  Not needed by the solve; provided for callers that inspect them. */
+int sfm_ba_calc_W_Y(const sfm_ba_plan* plan, const double* d_A, const double* d_B,
+                    const double* d_weights, const double* d_V_inv, const int32_t* d_pt_idx,
+                    double* d_W, double* d_Y, void* stream);
+
+/* Rebuild S rows/e from all-reduced per-camera records and add the damping: S_jj += U_j + mu I
+ * is already inside S for a single-rank run; a sharded run calls this after the all-reduce to
+ * add mu to the 7m diagonal entries of d_S (the one place mu enters U, src/sparse_ba.py:194-197). */
+int sfm_ba_add_diagonal(double* d_S, int32_t n7, double mu, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Reduced camera system.  Work of `calc_delta_a` (src/sparse_ba.py:274-276): solves
+ * S delta_a = e.  The reference calls LAPACK dgesv (LU); S is symmetric positive definite
+ * (it is the Schur complement of J^T J + mu I), and this library factors it by a blocked
+ * Cholesky on the device, in place.
+ *   d_S [(n7+1), n7] as written by sfm_ba_schur_assemble (row n7 = right-hand side); destroyed
+ *   d_delta_a [n7] out
+ *   d_chol_ws : sfm_ba_cholesky_workspace_bytes(n7) bytes
+ *   d_info [1] int32: 0, or 1+index of the first non-positive pivot (SFM_BA_ENOTPD semantics;
+ *          read it after synchronising the stream)
+ * ---------------------------------------------------------------------------------------- */
+int64_t sfm_ba_cholesky_workspace_bytes(int32_t n7);
+int sfm_ba_solve_reduced(double* d_S, int32_t n7, double* d_delta_a, void* d_chol_ws,
+                         int32_t* d_info, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Back-substitution.  Work of `calc_delta_b` (src/sparse_ba.py:279-290):
+ * delta_b_i = V_inv_i (eps_b_i - sum_j W_ij^T delta_a_j).
+ *   d_delta_b [n,3] out.  If d_X_update is not NULL, X_update[i] += x_step * delta_b[i]
+ *   (the point update of src/bundle_adjustment.py:100 with x_step = 0.5).
+ * ---------------------------------------------------------------------------------------- */
+int sfm_ba_back_substitute(const sfm_ba_plan* plan, const double* d_A, const double* d_B,
+                           const double* d_weights, const double* d_V_inv, const double* d_eps_b,
+                           const double* d_delta_a, double* d_delta_b, double* d_X_update,
+                           double x_step, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Camera update.  Work of the per-frame body of `optimize_using_BA`
+ * (src/bundle_adjustment.py:82-98) with `quaternion_to_rotation_matrix` (src/utils.py:25-59) and
+ * `Frame.compute_projection_matrix` (src/frame.py:50-53): for every camera >= first_cam
+ * Q = quat(R) + q_step*delta_a[0:4], normalised; R = rot(Q); C' = C + c_step*delta_a[4:7];
+ * T = -R C'; C = -R^T T; P = K [R|T] (d_K [m,9] or [1,9], k_stride 9 or 0; d_P may be NULL).
+ * The reference skips frame 0 (first_cam = 1) and uses
+ * q_step = 1, c_step = 0.1.  d_flags [m] receives SFM_BA_FLAG_ZERO_QUAT where the reference
+ * would raise ValueError.
+ * ---------------------------------------------------------------------------------------- */
+int sfm_ba_update_cameras(double* d_R, double* d_T, double* d_C, double* d_P, const double* d_K,
+                          int k_stride, const double* d_delta_a, int32_t m, int32_t first_cam,
+                          double q_step, double c_step, int32_t* d_flags, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Cost.  Work of `compute_reprojection_error_total` (src/bundle_adjustment.py:9-19): per camera
+ * the sum of squared residuals of its observations; d_cam_ssq [m] out.  The caller (after an
+ * all-reduce in a sharded run) takes mean_j sqrt(ssq_j); sfm_ba_cost_finish does that on the
+ * device: d_cost[0] = sum_j sqrt(d_cam_ssq[j]) / m.
+ * ---------------------------------------------------------------------------------------- */
+int sfm_ba_cost_partial(const sfm_ba_plan* plan, const double* d_P, const double* d_X,
+                        const int32_t* d_cam_idx, const int32_t* d_pt_idx, const double* d_x_true,
+                        double* d_cam_ssq, void* d_workspace, void* stream);
+int sfm_ba_cost_finish(const double* d_cam_ssq, int32_t m, double* d_cost, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFM_BA_H */

@@ -1,0 +1,95 @@
+"""ctypes binding of ``csrc/libsfm_ba.so`` (the C ABI declared in ``include/sfm_ba.h``).
+
+The library is the only compute path of this package: if it is missing the import
+of any compute module fails with an explicit error - there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsfm_ba.so")
+
+OK = 0
+EINVAL, EHIP, ENONUNIQUE, EMISSING_POINT, EMISSING_VIEW, ENOTPD, ETOOBIG = -1, -2, -3, -4, -5, -6, -7
+CAM_BLK = 56
+CAM_RED = 43
+FLAG_DET_NOT_ONE, FLAG_ZERO_QUAT, FLAG_NONFINITE = 1, 2, 4
+
+# every symbol include/sfm_ba.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64, _f64, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_int
+SYMBOLS = {
+    "sfm_ba_version": (_int, []),
+    "sfm_ba_error_string": (C.c_char_p, [_int]),
+    "sfm_ba_last_hip_error": (C.c_char_p, []),
+    "sfm_ba_plan_create": (_int, [_vp, _vp, _i64, _i32, _i32, _int, C.POINTER(_vp)]),
+    "sfm_ba_plan_destroy": (None, [_vp]),
+    "sfm_ba_plan_sizes": (_int, [_vp, C.POINTER(_i64)]),
+    "sfm_ba_plan_workspace_bytes": (_i64, [_vp]),
+    "sfm_ba_camera_prepare": (_int, [_vp, _vp, _vp, _int, _i32, _vp, _vp, _vp]),
+    "sfm_ba_jacobian": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "sfm_ba_schur_assemble": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sfm_ba_calc_W_Y": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sfm_ba_add_diagonal": (_int, [_vp, _i32, _f64, _vp]),
+    "sfm_ba_cholesky_workspace_bytes": (_i64, [_i32]),
+    "sfm_ba_solve_reduced": (_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
+    "sfm_ba_back_substitute": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp]),
+    "sfm_ba_update_cameras": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _i32, _i32, _f64, _f64, _vp, _vp]),
+    "sfm_ba_cost_partial": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sfm_ba_cost_finish": (_int, [_vp, _i32, _vp, _vp]),
+}
+
+_lib = None
+
+
+class SfmBaError(RuntimeError):
+    """A failure reported by libsfm_ba.so that has no counterpart in the reference."""
+
+
+def load():
+    """Load the shared library (once) and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950).  This package has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sfm_ba_version() != 1:
+        raise ImportError("libsfm_ba.so version mismatch")
+    _lib = lib
+    return lib
+
+
+def error_string(code: int) -> str:
+    return load().sfm_ba_error_string(code).decode()
+
+
+def check(rc: int):
+    """Translate a status code into the exception the reference raises in the same situation."""
+    if rc == OK:
+        return
+    if rc == ENONUNIQUE:
+        raise ValueError("Found non-unique (i, j) pair")  # src/sparse_ba.py:62
+    if rc in (EMISSING_POINT, EMISSING_VIEW):
+        raise AssertionError(error_string(rc))  # src/sparse_ba.py:89,91
+    if rc == ENOTPD:
+        raise np.linalg.LinAlgError("Singular matrix")  # numpy.linalg.solve at src/sparse_ba.py:275
+    msg = error_string(rc)
+    if rc == EHIP:
+        msg += ": " + load().sfm_ba_last_hip_error().decode()
+    raise SfmBaError(msg)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

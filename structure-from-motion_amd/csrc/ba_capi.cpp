@@ -1,0 +1,100 @@
+// extern "C" surface of libsfm_ba.so: argument checks, then the kernel launchers.
+#include "ba_common.h"
+
+using namespace sfmba;
+
+extern "C" {
+
+int sfm_ba_version(void) { return SFM_BA_VERSION; }
+
+const char* sfm_ba_error_string(int code) {
+  switch (code) {
+    case SFM_BA_OK: return "ok";
+    case SFM_BA_EINVAL: return "invalid argument";
+    case SFM_BA_EHIP: return "HIP runtime error";
+    case SFM_BA_ENONUNIQUE: return "Found non-unique (i, j) pair";
+    case SFM_BA_EMISSING_POINT: return "point indices are not contiguous";
+    case SFM_BA_EMISSING_VIEW: return "viewpoint indices are not contiguous";
+    case SFM_BA_ENOTPD: return "reduced camera system is not positive definite";
+    case SFM_BA_ETOOBIG: return "a point has too many observations or the problem exceeds int32 indexing";
+    default: return "unknown error";
+  }
+}
+
+int sfm_ba_camera_prepare(const double* d_R, const double* d_C, const double* d_K, int k_stride, int32_t m,
+                          double* d_cam_blk, int32_t* d_flags, void* stream) {
+  if (!d_R || !d_C || !d_K || !d_cam_blk || m < 0 || (k_stride != 0 && k_stride != 9)) return SFM_BA_EINVAL;
+  return launch_camera_prepare(d_R, d_C, d_K, k_stride, m, d_cam_blk, d_flags, static_cast<hipStream_t>(stream));
+}
+
+int sfm_ba_jacobian(const double* d_cam_blk, const double* d_P, const double* d_X, const int32_t* d_cam_idx,
+                    const int32_t* d_pt_idx, int64_t n_obs, double* d_A, double* d_B, double* d_x_pred,
+                    void* stream) {
+  if (!d_cam_blk || !d_X || !d_cam_idx || !d_pt_idx || n_obs < 0) return SFM_BA_EINVAL;
+  if (d_x_pred && !d_P) return SFM_BA_EINVAL;
+  if (n_obs >= (int64_t(1) << 31)) return SFM_BA_ETOOBIG;
+  return launch_jacobian(d_cam_blk, d_P, d_X, d_cam_idx, d_pt_idx, n_obs, d_A, d_B, d_x_pred,
+                         static_cast<hipStream_t>(stream));
+}
+
+int sfm_ba_schur_assemble(const sfm_ba_plan* plan, const double* d_A, const double* d_B, const double* d_x_true,
+                          const double* d_x_pred, const double* d_weights, double mu, double mu_u, double* d_S,
+                          double* d_e, double* d_U, double* d_eps_a, double* d_V_inv, double* d_eps_b,
+                          double* d_cam_red, void* d_workspace, void* stream) {
+  if (!plan || !d_A || !d_B || !d_x_true || !d_x_pred || !d_V_inv || !d_eps_b || !d_workspace) return SFM_BA_EINVAL;
+  if (!(mu >= 0.0) || !(mu_u >= 0.0)) return SFM_BA_EINVAL;
+  return launch_assemble(plan, d_A, d_B, d_x_true, d_x_pred, d_weights, mu, mu_u, d_S, d_e, d_U, d_eps_a, d_V_inv,
+                         d_eps_b, d_cam_red, d_workspace, static_cast<hipStream_t>(stream));
+}
+
+int sfm_ba_calc_W_Y(const sfm_ba_plan* plan, const double* d_A, const double* d_B, const double* d_weights,
+                    const double* d_V_inv, const int32_t* d_pt_idx, double* d_W, double* d_Y, void* stream) {
+  if (!plan || !d_A || !d_B || !d_V_inv || !d_pt_idx) return SFM_BA_EINVAL;
+  return launch_calc_W_Y(plan, d_A, d_B, d_weights, d_V_inv, d_pt_idx, d_W, d_Y, static_cast<hipStream_t>(stream));
+}
+
+int sfm_ba_add_diagonal(double* d_S, int32_t n7, double mu, void* stream) {
+  if (!d_S || n7 < 0) return SFM_BA_EINVAL;
+  return launch_add_diagonal(d_S, n7, mu, static_cast<hipStream_t>(stream));
+}
+
+int64_t sfm_ba_cholesky_workspace_bytes(int32_t n7) { return n7 > 0 ? cholesky_workspace_bytes(n7) : 0; }
+
+int sfm_ba_solve_reduced(double* d_S, int32_t n7, double* d_delta_a, void* d_chol_ws, int32_t* d_info,
+                         void* stream) {
+  if (!d_S || !d_delta_a || !d_chol_ws || !d_info || n7 <= 0) return SFM_BA_EINVAL;
+  return launch_solve_reduced(d_S, n7, d_delta_a, d_chol_ws, d_info, static_cast<hipStream_t>(stream));
+}
+
+int sfm_ba_back_substitute(const sfm_ba_plan* plan, const double* d_A, const double* d_B, const double* d_weights,
+                           const double* d_V_inv, const double* d_eps_b, const double* d_delta_a,
+                           double* d_delta_b, double* d_X_update, double x_step, void* stream) {
+  if (!plan || !d_A || !d_B || !d_V_inv || !d_eps_b || !d_delta_a || !d_delta_b) return SFM_BA_EINVAL;
+  return launch_back_substitute(plan, d_A, d_B, d_weights, d_V_inv, d_eps_b, d_delta_a, d_delta_b, d_X_update,
+                                x_step, static_cast<hipStream_t>(stream));
+}
+
+int sfm_ba_update_cameras(double* d_R, double* d_T, double* d_C, double* d_P, const double* d_K, int k_stride,
+                          const double* d_delta_a, int32_t m, int32_t first_cam, double q_step, double c_step,
+                          int32_t* d_flags, void* stream) {
+  if (!d_R || !d_T || !d_C || !d_K || !d_delta_a || m < 0 || first_cam < 0 || (k_stride != 0 && k_stride != 9))
+    return SFM_BA_EINVAL;
+  return launch_update_cameras(d_R, d_T, d_C, d_P, d_K, k_stride, d_delta_a, m, first_cam, q_step, c_step, d_flags,
+                               static_cast<hipStream_t>(stream));
+}
+
+int sfm_ba_cost_partial(const sfm_ba_plan* plan, const double* d_P, const double* d_X, const int32_t* d_cam_idx,
+                        const int32_t* d_pt_idx, const double* d_x_true, double* d_cam_ssq, void* d_workspace,
+                        void* stream) {
+  if (!plan || !d_P || !d_X || !d_cam_idx || !d_pt_idx || !d_x_true || !d_cam_ssq || !d_workspace)
+    return SFM_BA_EINVAL;
+  return launch_cost_partial(plan, d_P, d_X, d_cam_idx, d_pt_idx, d_x_true, d_cam_ssq, d_workspace,
+                             static_cast<hipStream_t>(stream));
+}
+
+int sfm_ba_cost_finish(const double* d_cam_ssq, int32_t m, double* d_cost, void* stream) {
+  if (!d_cam_ssq || !d_cost || m <= 0) return SFM_BA_EINVAL;
+  return launch_cost_finish(d_cam_ssq, m, d_cost, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+// Internal declarations shared by the translation units of libsfm_ba.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sfm_ba.h"
+
+namespace sfmba {
+
+// ---- tunables -------------------------------------------------------------------------------
+constexpr int kGroupSlots = 256;   // observations handled by one workgroup of the per-point kernels
+constexpr int kCamChunk = 1024;    // observations per per-camera work item
+constexpr int kCamThreads = 128;   // threads of a per-camera work item
+constexpr int kPairChunk = 512;    // (obs, obs) entries per camera-pair work item (one wave each)
+
+struct PairEntry {
+  int32_t obs_a;  // observation (caller order) of the block's row camera j
+  int32_t obs_b;  // observation of the block's column camera k (same point)
+  int32_t tslot;  // index of the point's 2x2 coupling matrix for this pair
+  int32_t pad;
+};
+
+}  // namespace sfmba
+
+// Opaque plan: device-resident index structures of one visibility pattern.
+struct sfm_ba_plan {
+  int32_t m = 0, n = 0;
+  int64_t n_obs = 0;
+  // observations grouped by point ("slots"; inside a point, cameras ascend)
+  int32_t* d_pt_ptr = nullptr;    // [n+1]
+  int32_t* d_perm = nullptr;      // [N] slot -> observation position in caller order
+  int32_t* d_slot_cam = nullptr;  // [N] camera of the slot
+  int32_t* d_tp_ptr = nullptr;    // [n+1] first pair slot of the point (k(k+1)/2 per point)
+  int32_t* d_grp_pt = nullptr;    // [n_groups+1] first point of each workgroup's range
+  int32_t n_groups = 0;
+  int64_t n_pair_slots = 0;
+  // per-camera work items over the camera-sorted observation list
+  int32_t* d_cam_obs = nullptr;   // [N] or null when the caller order is already camera-sorted
+  int32_t* d_item_cam = nullptr;  // [n_items]
+  int32_t* d_item_beg = nullptr;  // [n_items] range in the camera-sorted list
+  int32_t* d_item_end = nullptr;
+  int32_t* d_cam_item_ptr = nullptr;  // [m+1]
+  int32_t n_items = 0;
+  // camera-pair blocks (j <= k) with at least one shared point
+  int32_t n_blocks = 0;
+  int32_t* d_blk_j = nullptr;
+  int32_t* d_blk_k = nullptr;
+  int64_t n_entries = 0;
+  sfmba::PairEntry* d_entries = nullptr;
+  // pair work items: chunk of one block's entries
+  int32_t n_pair_items = 0;
+  int32_t* d_pit_blk = nullptr;
+  int32_t* d_pit_beg = nullptr;
+  int32_t* d_pit_end = nullptr;
+  int32_t* d_pit_part = nullptr;  // -1: the block has one item and is written directly
+  int32_t n_parts = 0;            // partial 7x7 results of multi-item blocks
+  int32_t n_multi = 0;            // blocks with more than one item
+  int32_t* d_mb_blk = nullptr;
+  int32_t* d_mb_part = nullptr;   // first partial
+  int32_t* d_mb_cnt = nullptr;    // number of partials
+  int64_t device_bytes = 0;
+  // workspace section offsets (bytes)
+  int64_t ws_g = 0, ws_T = 0, ws_campart = 0, ws_spart = 0, ws_total = 0;
+};
+
+namespace sfmba {
+
+void set_hip_error(hipError_t err, const char* what);
+
+#define SFMBA_HIP(call)                         \
+  do {                                          \
+    hipError_t err__ = (call);                  \
+    if (err__ != hipSuccess) {                  \
+      sfmba::set_hip_error(err__, #call);       \
+      return SFM_BA_EHIP;                       \
+    }                                           \
+  } while (0)
+
+// launchers implemented in ba_kernels.hip / ba_cholesky.hip
+int launch_camera_prepare(const double* R, const double* C, const double* K, int k_stride, int m,
+                          double* blk, int32_t* flags, hipStream_t st);
+int launch_jacobian(const double* blk, const double* P, const double* X, const int32_t* cam,
+                    const int32_t* pt, int64_t N, double* A, double* B, double* xp, hipStream_t st);
+int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, const double* xt,
+                    const double* xp, const double* w, double mu, double mu_u, double* S, double* e,
+                    double* U, double* eps_a, double* Vinv, double* eps_b, double* cam_red,
+                    void* ws, hipStream_t st);
+int launch_calc_W_Y(const sfm_ba_plan* p, const double* A, const double* B, const double* w,
+                    const double* Vinv, const int32_t* pt, double* W, double* Y, hipStream_t st);
+int launch_add_diagonal(double* S, int n7, double mu, hipStream_t st);
+int launch_back_substitute(const sfm_ba_plan* p, const double* A, const double* B, const double* w,
+                           const double* Vinv, const double* eps_b, const double* da, double* db,
+                           double* Xupd, double x_step, hipStream_t st);
+int launch_update_cameras(double* R, double* T, double* C, double* P, const double* K, int k_stride,
+                          const double* da, int m, int first, double q_step, double c_step,
+                          int32_t* flags, hipStream_t st);
+int launch_cost_partial(const sfm_ba_plan* p, const double* P, const double* X, const int32_t* cam,
+                        const int32_t* pt, const double* xt, double* ssq, void* ws, hipStream_t st);
+int launch_cost_finish(const double* ssq, int m, double* cost, hipStream_t st);
+int64_t cholesky_workspace_bytes(int n7);
+int launch_solve_reduced(double* S, int n7, double* da, void* ws, int32_t* info, hipStream_t st);
+
+}  // namespace sfmba

@@ -1,0 +1,855 @@
+// Bundle-adjustment kernels for gfx950 (MI355X): per-camera records, per-observation
+// Jacobians, Schur assembly, back-substitution, camera update and cost.  fp64 throughout.
+//
+// Layout conventions
+//   A [N,2,7]  row a (0 = x pixel, 1 = y pixel) of observation i starts at A + 14*i + 7*a
+//   B [N,2,3]  row a at B + 6*i + 3*a
+//   "slot"     position of an observation in the plan's point-major order; perm[slot] is
+//              its position in the caller's order, which is the order of A, B, x_true, x_pred
+//   S          dense (7m+1) x 7m row-major; row 7m carries the right-hand side e
+//
+// Every reduction runs in a fixed order (no atomics), so results are reproducible bit for bit.
+#include "ba_common.h"
+
+namespace sfmba {
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
+__device__ __forceinline__ void st2(double* p, double a, double b) {
+  *reinterpret_cast<double2*>(p) = make_double2(a, b);
+}
+
+// Rotation matrix (row-major) -> quaternion [x,y,z,w]; the four cases of the reference's
+// conversion, selected by the same comparisons.
+__device__ __forceinline__ void rot_to_quat(const double* R, double* Q) {
+  const double tr = R[0] + R[4] + R[8];
+  double x, y, z, w;
+  if (tr > 0.0) {
+    const double s = 0.5 / sqrt(tr + 1.0);
+    w = 0.25 / s;
+    x = (R[7] - R[5]) * s;
+    y = (R[2] - R[6]) * s;
+    z = (R[3] - R[1]) * s;
+  } else if (R[0] > R[4] && R[0] > R[8]) {
+    const double s = 2.0 * sqrt(1.0 + R[0] - R[4] - R[8]);
+    w = (R[7] - R[5]) / s;
+    x = 0.25 * s;
+    y = (R[1] + R[3]) / s;
+    z = (R[2] + R[6]) / s;
+  } else if (R[4] > R[8]) {
+    const double s = 2.0 * sqrt(1.0 + R[4] - R[0] - R[8]);
+    w = (R[2] - R[6]) / s;
+    x = (R[1] + R[3]) / s;
+    y = 0.25 * s;
+    z = (R[5] + R[7]) / s;
+  } else {
+    const double s = 2.0 * sqrt(1.0 + R[8] - R[0] - R[4]);
+    w = (R[3] - R[1]) / s;
+    x = (R[2] + R[6]) / s;
+    y = (R[5] + R[7]) / s;
+    z = 0.25 * s;
+  }
+  Q[0] = x; Q[1] = y; Q[2] = z; Q[3] = w;
+}
+
+__device__ __forceinline__ void quat_to_rot(const double* q, double* R) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double xx = x * x, xy = x * y, xz = x * z, xw = x * w;
+  const double yy = y * y, yz = y * z, yw = y * w, zz = z * z, zw = z * w;
+  R[0] = 1 - 2 * (yy + zz); R[1] = 2 * (xy - zw);     R[2] = 2 * (xz + yw);
+  R[3] = 2 * (xy + zw);     R[4] = 1 - 2 * (xx + zz); R[5] = 2 * (yz - xw);
+  R[6] = 2 * (xz - yw);     R[7] = 2 * (yz + xw);     R[8] = 1 - 2 * (xx + yy);
+}
+
+__device__ __forceinline__ double det3(const double* R) {
+  return R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) +
+         R[2] * (R[3] * R[7] - R[4] * R[6]);
+}
+
+// ------------------------------------------------------------------------------------------
+// per-camera record
+// ------------------------------------------------------------------------------------------
+__global__ void k_camera_prepare(const double* __restrict__ R, const double* __restrict__ C,
+                                 const double* __restrict__ K, int k_stride, int m,
+                                 double* __restrict__ blk, int32_t* __restrict__ flags) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const double* r = R + 9 * (int64_t)j;
+  const double* k = K + (int64_t)k_stride * j;
+  double* o = blk + (int64_t)SFM_BA_CAM_BLK * j;
+  const double fx = k[0], fy = k[4], ox = k[2], oy = k[5];
+  double rr[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) rr[i] = r[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    o[i] = fx * rr[i] + ox * rr[6 + i];
+    o[3 + i] = fy * rr[3 + i] + oy * rr[6 + i];
+    o[6 + i] = rr[6 + i];
+    o[9 + i] = C[3 * (int64_t)j + i];
+  }
+  double q[4];
+  rot_to_quat(rr, q);
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  // dR/dQ, rows R11 R12 R13 R21 R22 R23 R31 R32 R33, columns d/dx d/dy d/dz d/dw,
+  // with the signs of the reference's table
+  const double g[36] = {
+      0, -4 * y, -4 * z, 0,           //
+      2 * y, 2 * x, -2 * w, 2 * z,    //
+      2 * z, 2 * w, 2 * x, 2 * y,     //
+      2 * y, 2 * x, 2 * w, 2 * z,     //
+      -4 * x, 0, -4 * z, 0,           //
+      -2 * w, 2 * z, 2 * y, 2 * x,    //
+      2 * z, -2 * w, -2 * x, -2 * y,  //
+      2 * w, 2 * z, 2 * y, 2 * x,     //
+      -4 * x, -4 * y, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 36; ++i) o[12 + i] = g[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[48 + i] = q[i];
+  o[52] = fx; o[53] = fy; o[54] = ox; o[55] = oy;
+  int f = 0;
+  const double det = det3(rr);
+  if (!(fabs(det - 1.0) <= 1e-8 + 1e-5)) f |= SFM_BA_FLAG_DET_NOT_ONE;
+  double chk = 0;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) chk += o[i];
+  if (!isfinite(chk)) f |= SFM_BA_FLAG_NONFINITE;
+  if (flags) flags[j] = f;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-observation Jacobian blocks and prediction: one lane per observation
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_jacobian(
+    const double* __restrict__ blk, const double* __restrict__ P, const double* __restrict__ X,
+    const int32_t* __restrict__ cam, const int32_t* __restrict__ pt, int64_t N,
+    double* __restrict__ A, double* __restrict__ B, double* __restrict__ xp) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int c = cam[i];
+  const int p = pt[i];
+  const double* cb = blk + (int64_t)SFM_BA_CAM_BLK * c;
+  const double x0 = X[3 * (int64_t)p], x1 = X[3 * (int64_t)p + 1], x2 = X[3 * (int64_t)p + 2];
+
+  if (xp) {
+    const double* pm = P + 12 * (int64_t)c;
+    const double h0 = pm[0] * x0 + pm[1] * x1 + pm[2] * x2 + pm[3];
+    const double h1 = pm[4] * x0 + pm[5] * x1 + pm[6] * x2 + pm[7];
+    const double h2 = pm[8] * x0 + pm[9] * x1 + pm[10] * x2 + pm[11];
+    st2(xp + 2 * i, h0 / h2, h1 / h2);
+  }
+  if (!A && !B) return;
+
+  double mu_[3], mv_[3], mw_[3], d[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    mu_[k] = cb[k];
+    mv_[k] = cb[3 + k];
+    mw_[k] = cb[6 + k];
+  }
+  d[0] = x0 - cb[9];
+  d[1] = x1 - cb[10];
+  d[2] = x2 - cb[11];
+  const double u = mu_[0] * d[0] + mu_[1] * d[1] + mu_[2] * d[2];
+  const double v = mv_[0] * d[0] + mv_[1] * d[1] + mv_[2] * d[2];
+  const double w = mw_[0] * d[0] + mw_[1] * d[1] + mw_[2] * d[2];
+  const double w2 = w * w;
+  double b0[3], b1[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    b0[k] = (w * mu_[k] - u * mw_[k]) / w2;
+    b1[k] = (w * mv_[k] - v * mw_[k]) / w2;
+  }
+  if (B) {
+    double* o = B + 6 * i;
+    st2(o, b0[0], b0[1]);
+    st2(o + 2, b0[2], b1[0]);
+    st2(o + 4, b1[1], b1[2]);
+  }
+  if (A) {
+    const double fx = cb[52], fy = cb[53], ox = cb[54], oy = cb[55];
+    // gq[r][q] = sum_i d[i] * dRdQ[3r+i][q]
+    double a0[4], a1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double g0 = d[0] * cb[12 + 0 + q] + d[1] * cb[12 + 4 + q] + d[2] * cb[12 + 8 + q];
+      const double g1 = d[0] * cb[12 + 12 + q] + d[1] * cb[12 + 16 + q] + d[2] * cb[12 + 20 + q];
+      const double g2 = d[0] * cb[12 + 24 + q] + d[1] * cb[12 + 28 + q] + d[2] * cb[12 + 32 + q];
+      const double du = fx * g0 + ox * g2;
+      const double dv = fy * g1 + oy * g2;
+      a0[q] = (w * du - u * g2) / w2;
+      a1[q] = (w * dv - v * g2) / w2;
+    }
+    double* o = A + 14 * i;
+    st2(o, a0[0], a0[1]);
+    st2(o + 2, a0[2], a0[3]);
+    st2(o + 4, -b0[0], -b0[1]);
+    st2(o + 6, -b0[2], a1[0]);
+    st2(o + 8, a1[1], a1[2]);
+    st2(o + 10, a1[3], -b1[0]);
+    st2(o + 12, -b1[1], -b1[2]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-point stage: V_i, V_i^-1, eps_b_i, then per observation g = w (eps - B V^-1 eps_b) and per
+// observation pair (a <= b) of the point the 2x2 coupling T_ab = (wB)_a V^-1 (wB)_b^T.
+// One workgroup owns a run of points with at most kGroupSlots observations; one lane per
+// observation, then one lane per point.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_point(
+    const int32_t* __restrict__ grp_pt, const int32_t* __restrict__ pt_ptr,
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ tp_ptr,
+    const double* __restrict__ B, const double* __restrict__ xt, const double* __restrict__ xpred,
+    const double* __restrict__ wgt, double mu, double* __restrict__ Vinv,
+    double* __restrict__ eps_b, double* __restrict__ g, double* __restrict__ T) {
+  __shared__ double sBp[kGroupSlots * 6];
+  __shared__ double sCon[kGroupSlots * 9];
+  __shared__ double sVz[kGroupSlots * 9];
+  __shared__ int sPtr[kGroupSlots + 1];
+  __shared__ int sLp[kGroupSlots];
+  const int t = threadIdx.x;
+  const int p0 = grp_pt[blockIdx.x];
+  const int np = grp_pt[blockIdx.x + 1] - p0;
+  for (int i = t; i <= np; i += 256) sPtr[i] = pt_ptr[p0 + i];
+  __syncthreads();
+  const int s0 = sPtr[0];
+  const int ns = sPtr[np] - s0;
+  if (t < np)
+    for (int s = sPtr[t]; s < sPtr[t + 1]; ++s) sLp[s - s0] = t;
+
+  double bp[6], we[2];
+  int pos = 0;
+  if (t < ns) {
+    pos = perm[s0 + t];
+    const double* b = B + 6 * (int64_t)pos;
+    const double2 b01 = ld2(b), b23 = ld2(b + 2), b45 = ld2(b + 4);
+    const double bb[6] = {b01.x, b01.y, b23.x, b23.y, b45.x, b45.y};
+    const double2 xa = ld2(xt + 2 * (int64_t)pos), xb = ld2(xpred + 2 * (int64_t)pos);
+    const double e0 = xa.x - xb.x, e1 = xa.y - xb.y;
+    double w00 = 1.0, w01 = 0.0, w10 = 0.0, w11 = 1.0;
+    if (wgt) {
+      const double* wp = wgt + 4 * (int64_t)pos;
+      w00 = wp[0]; w01 = wp[1]; w10 = wp[2]; w11 = wp[3];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      bp[q] = w00 * bb[q] + w01 * bb[3 + q];
+      bp[3 + q] = w10 * bb[q] + w11 * bb[3 + q];
+    }
+    we[0] = w00 * e0 + w01 * e1;
+    we[1] = w10 * e0 + w11 * e1;
+    double* c = sCon + 9 * t;
+    // B^T w B (symmetric: 00 01 02 11 12 22) and B^T w eps
+    c[0] = bb[0] * bp[0] + bb[3] * bp[3];
+    c[1] = bb[0] * bp[1] + bb[3] * bp[4];
+    c[2] = bb[0] * bp[2] + bb[3] * bp[5];
+    c[3] = bb[1] * bp[1] + bb[4] * bp[4];
+    c[4] = bb[1] * bp[2] + bb[4] * bp[5];
+    c[5] = bb[2] * bp[2] + bb[5] * bp[5];
+    c[6] = bb[0] * we[0] + bb[3] * we[1];
+    c[7] = bb[1] * we[0] + bb[4] * we[1];
+    c[8] = bb[2] * we[0] + bb[5] * we[1];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) sBp[6 * t + q] = bp[q];
+  }
+  __syncthreads();
+  if (t < np) {
+    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = sPtr[t] - s0; s < sPtr[t + 1] - s0; ++s) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) a[q] += sCon[9 * s + q];
+    }
+    const double v00 = a[0] + mu, v01 = a[1], v02 = a[2], v11 = a[3] + mu, v12 = a[4], v22 = a[5] + mu;
+    const double c00 = v11 * v22 - v12 * v12;
+    const double c01 = v02 * v12 - v01 * v22;
+    const double c02 = v01 * v12 - v02 * v11;
+    const double c11 = v00 * v22 - v02 * v02;
+    const double c12 = v01 * v02 - v00 * v12;
+    const double c22 = v00 * v11 - v01 * v01;
+    const double det = v00 * c00 + v01 * c01 + v02 * c02;
+    const double id = 1.0 / det;
+    const double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id, i11 = c11 * id, i12 = c12 * id, i22 = c22 * id;
+    double* vz = sVz + 9 * t;
+    vz[0] = i00; vz[1] = i01; vz[2] = i02; vz[3] = i11; vz[4] = i12; vz[5] = i22;
+    vz[6] = i00 * a[6] + i01 * a[7] + i02 * a[8];
+    vz[7] = i01 * a[6] + i11 * a[7] + i12 * a[8];
+    vz[8] = i02 * a[6] + i12 * a[7] + i22 * a[8];
+    double* vo = Vinv + 9 * (int64_t)(p0 + t);
+    vo[0] = i00; vo[1] = i01; vo[2] = i02;
+    vo[3] = i01; vo[4] = i11; vo[5] = i12;
+    vo[6] = i02; vo[7] = i12; vo[8] = i22;
+    double* eo = eps_b + 3 * (int64_t)(p0 + t);
+    eo[0] = a[6]; eo[1] = a[7]; eo[2] = a[8];
+  }
+  __syncthreads();
+  if (t < ns) {
+    const int lp = sLp[t];
+    const double* vz = sVz + 9 * lp;
+    const double i00 = vz[0], i01 = vz[1], i02 = vz[2], i11 = vz[3], i12 = vz[4], i22 = vz[5];
+    const double z0 = vz[6], z1 = vz[7], z2 = vz[8];
+    st2(g + 2 * (int64_t)pos, we[0] - (bp[0] * z0 + bp[1] * z1 + bp[2] * z2),
+        we[1] - (bp[3] * z0 + bp[4] * z1 + bp[5] * z2));
+    // H = (wB)_a V^-1  (2x3)
+    const double h00 = bp[0] * i00 + bp[1] * i01 + bp[2] * i02;
+    const double h01 = bp[0] * i01 + bp[1] * i11 + bp[2] * i12;
+    const double h02 = bp[0] * i02 + bp[1] * i12 + bp[2] * i22;
+    const double h10 = bp[3] * i00 + bp[4] * i01 + bp[5] * i02;
+    const double h11 = bp[3] * i01 + bp[4] * i11 + bp[5] * i12;
+    const double h12 = bp[3] * i02 + bp[4] * i12 + bp[5] * i22;
+    const int first = sPtr[lp] - s0;
+    const int k = sPtr[lp + 1] - sPtr[lp];
+    const int a = t - first;
+    int64_t ts = (int64_t)tp_ptr[p0 + lp] + (int64_t)a * k - (int64_t)a * (a - 1) / 2;
+    for (int b = a; b < k; ++b, ++ts) {
+      const double* q = sBp + 6 * (first + b);
+      double* o = T + 4 * ts;
+      st2(o, h00 * q[0] + h01 * q[1] + h02 * q[2], h00 * q[3] + h01 * q[4] + h02 * q[5]);
+      st2(o + 2, h10 * q[0] + h11 * q[1] + h12 * q[2], h10 * q[3] + h11 * q[4] + h12 * q[5]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-camera sums over a work item (a chunk of one camera's observations):
+//   [0..27] upper triangle of sum A^T w A, [28..34] sum A^T w eps, [35..41] sum A^T g, [42] sum |eps|^2
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kCamThreads) void k_camera_items(
+    const int32_t* __restrict__ item_beg, const int32_t* __restrict__ item_end,
+    const int32_t* __restrict__ cam_obs, const double* __restrict__ A, const double* __restrict__ xt,
+    const double* __restrict__ xpred, const double* __restrict__ wgt, const double* __restrict__ g,
+    double* __restrict__ part) {
+  __shared__ double red[SFM_BA_CAM_RED * (kCamThreads + 1)];
+  const int t = threadIdx.x;
+  const int beg = item_beg[blockIdx.x], end = item_end[blockIdx.x];
+  double acc[SFM_BA_CAM_RED];
+#pragma unroll
+  for (int v = 0; v < SFM_BA_CAM_RED; ++v) acc[v] = 0.0;
+  for (int i = beg + t; i < end; i += kCamThreads) {
+    const int64_t pos = cam_obs ? cam_obs[i] : i;
+    const double* ap = A + 14 * pos;
+    double a[14];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const double2 v2 = ld2(ap + 2 * q);
+      a[2 * q] = v2.x;
+      a[2 * q + 1] = v2.y;
+    }
+    const double2 xa = ld2(xt + 2 * pos), xb = ld2(xpred + 2 * pos), gg = ld2(g + 2 * pos);
+    const double e0 = xa.x - xb.x, e1 = xa.y - xb.y;
+    double w00 = 1.0, w01 = 0.0, w10 = 0.0, w11 = 1.0;
+    if (wgt) {
+      const double* wp = wgt + 4 * pos;
+      w00 = wp[0]; w01 = wp[1]; w10 = wp[2]; w11 = wp[3];
+    }
+    const double we0 = w00 * e0 + w01 * e1, we1 = w10 * e0 + w11 * e1;
+    int v = 0;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      const double wa0 = w00 * a[r] + w10 * a[7 + r];  // (A^T w) row r, column 0
+      const double wa1 = w01 * a[r] + w11 * a[7 + r];
+#pragma unroll
+      for (int c = r; c < 7; ++c) acc[v++] += wa0 * a[c] + wa1 * a[7 + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      acc[28 + r] += a[r] * we0 + a[7 + r] * we1;
+      acc[35 + r] += a[r] * gg.x + a[7 + r] * gg.y;
+    }
+    acc[42] += e0 * e0 + e1 * e1;
+  }
+#pragma unroll
+  for (int v = 0; v < SFM_BA_CAM_RED; ++v) red[v * (kCamThreads + 1) + t] = acc[v];
+  __syncthreads();
+  // two lanes per value, each sums half of the lanes in ascending order, then the halves are added
+  __shared__ double half[SFM_BA_CAM_RED * 2];
+  if (t < 2 * SFM_BA_CAM_RED) {
+    const int v = t >> 1, h = t & 1;
+    const double* r = red + v * (kCamThreads + 1) + h * (kCamThreads / 2);
+    double s = 0.0;
+    for (int i = 0; i < kCamThreads / 2; ++i) s += r[i];
+    half[t] = s;
+  }
+  __syncthreads();
+  if (t < SFM_BA_CAM_RED) part[(int64_t)blockIdx.x * SFM_BA_CAM_RED + t] = half[2 * t] + half[2 * t + 1];
+}
+
+// one workgroup (64 lanes) per camera: add the camera's item partials in order, add the damping,
+// expand U, form e = eps_a - sum Y eps_b, write row 7m of S
+__global__ __launch_bounds__(64) void k_camera_finish(
+    const int32_t* __restrict__ cam_item_ptr, const double* __restrict__ part, int m, double mu_u,
+    double* __restrict__ S, double* __restrict__ e, double* __restrict__ U, double* __restrict__ eps_a,
+    double* __restrict__ cam_red) {
+  __shared__ double s[SFM_BA_CAM_RED];
+  const int j = blockIdx.x, t = threadIdx.x;
+  if (t < SFM_BA_CAM_RED) {
+    double a = 0.0;
+    for (int it = cam_item_ptr[j]; it < cam_item_ptr[j + 1]; ++it) a += part[(int64_t)it * SFM_BA_CAM_RED + t];
+    s[t] = a;
+    if (cam_red) cam_red[(int64_t)j * SFM_BA_CAM_RED + t] = a;
+  }
+  __syncthreads();
+  if (t < 49 && U) {
+    const int r = t / 7, c = t % 7;
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    const int idx = lo * 7 - lo * (lo - 1) / 2 + (hi - lo);
+    U[(int64_t)j * 49 + t] = s[idx] + (r == c ? mu_u : 0.0);
+  }
+  if (t < 7) {
+    // e_j = sum A^T g  (g already holds w (eps - B V^-1 eps_b))
+    const double ev = s[35 + t];
+    if (e) e[(int64_t)j * 7 + t] = ev;
+    if (eps_a) eps_a[(int64_t)j * 7 + t] = s[28 + t];
+    if (S) S[(int64_t)(7 * m) * (7 * m) + 7 * j + t] = ev;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// camera-pair blocks: S_jk = delta_jk (U_j) - sum over entries A_a^T T A_b.  One wave per work item
+// (a chunk of one block's entries): lane = 8 * g + c, g = entry sub-index 0..7, c = column 0..6 of
+// the block; every lane keeps the 7 rows of its column.  The 8 partial columns are then combined
+// by a fixed xor-butterfly.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pair_blocks(
+    int n_items, const int32_t* __restrict__ pit_blk, const int32_t* __restrict__ pit_beg,
+    const int32_t* __restrict__ pit_end, const int32_t* __restrict__ pit_part,
+    const int32_t* __restrict__ blk_j, const int32_t* __restrict__ blk_k,
+    const PairEntry* __restrict__ ent, const double* __restrict__ A, const double* __restrict__ T,
+    const double* __restrict__ cam_part, const int32_t* __restrict__ cam_item_ptr, double mu_u, int m,
+    double* __restrict__ S, double* __restrict__ spart) {
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= n_items) return;
+  const int lane = threadIdx.x & 63;
+  const int gsub = lane >> 3, c = lane & 7;
+  const int cc = c < 7 ? c : 6;  // lane 7 of each group shadows column 6 and is never stored
+  const int beg = pit_beg[item], end = pit_end[item];
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int i = beg + gsub; i < end; i += 8) {
+    const PairEntry en = ent[i];
+    const double* aa = A + 14 * (int64_t)en.obs_a;
+    const double* ab = A + 14 * (int64_t)en.obs_b;
+    const double* tt = T + 4 * (int64_t)en.tslot;
+    const double2 t0 = ld2(tt), t1 = ld2(tt + 2);
+    const double b0 = ab[cc], b1 = ab[7 + cc];
+    const double p0 = t0.x * b0 + t0.y * b1;
+    const double p1 = t1.x * b0 + t1.y * b1;
+    double a[14];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const double2 v2 = ld2(aa + 2 * q);
+      a[2 * q] = v2.x;
+      a[2 * q + 1] = v2.y;
+    }
+#pragma unroll
+    for (int r = 0; r < 7; ++r) acc[r] += a[r] * p0 + a[7 + r] * p1;
+  }
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    double v = acc[r];
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    acc[r] = v;
+  }
+  if (gsub != 0 || c >= 7) return;
+  const int part = pit_part[item];
+  if (part >= 0) {
+    double* o = spart + (int64_t)part * 49;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) o[7 * r + c] = acc[r];
+    return;
+  }
+  const int b = pit_blk[item];
+  const int j = blk_j[b], k = blk_k[b];
+  const int64_t ld = 7 * (int64_t)m;
+  if (j == k) {
+    // U_j from the per-camera item partials (upper triangle, fixed order)
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      const int lo = r < c ? r : c, hi = r < c ? c : r;
+      const int idx = lo * 7 - lo * (lo - 1) / 2 + (hi - lo);
+      double u = 0.0;
+      for (int it = cam_item_ptr[j]; it < cam_item_ptr[j + 1]; ++it) u += cam_part[(int64_t)it * SFM_BA_CAM_RED + idx];
+      if (r == c) u += mu_u;
+      S[(7 * (int64_t)j + r) * ld + 7 * k + c] = u - acc[r];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      const double v = -acc[r];
+      S[(7 * (int64_t)j + r) * ld + 7 * k + c] = v;
+      S[(7 * (int64_t)k + c) * ld + 7 * j + r] = v;
+    }
+  }
+}
+
+// blocks whose entries were split over several work items: add the partials in item order
+__global__ __launch_bounds__(64) void k_pair_finish(
+    const int32_t* __restrict__ mb_blk, const int32_t* __restrict__ mb_part,
+    const int32_t* __restrict__ mb_cnt, const int32_t* __restrict__ blk_j,
+    const int32_t* __restrict__ blk_k, const double* __restrict__ spart,
+    const double* __restrict__ cam_part, const int32_t* __restrict__ cam_item_ptr, double mu_u, int m,
+    double* __restrict__ S) {
+  const int t = threadIdx.x;
+  if (t >= 49) return;
+  const int b = mb_blk[blockIdx.x];
+  const int p0 = mb_part[blockIdx.x], cnt = mb_cnt[blockIdx.x];
+  double a = 0.0;
+  for (int i = 0; i < cnt; ++i) a += spart[(int64_t)(p0 + i) * 49 + t];
+  const int j = blk_j[b], k = blk_k[b];
+  const int r = t / 7, c = t % 7;
+  const int64_t ld = 7 * (int64_t)m;
+  if (j == k) {
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    const int idx = lo * 7 - lo * (lo - 1) / 2 + (hi - lo);
+    double u = 0.0;
+    for (int it = cam_item_ptr[j]; it < cam_item_ptr[j + 1]; ++it) u += cam_part[(int64_t)it * SFM_BA_CAM_RED + idx];
+    if (r == c) u += mu_u;
+    S[(7 * (int64_t)j + r) * ld + 7 * k + c] = u - a;
+  } else {
+    S[(7 * (int64_t)j + r) * ld + 7 * k + c] = -a;
+    S[(7 * (int64_t)k + c) * ld + 7 * j + r] = -a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// W = A^T w B and Y = W V^-1[point] per observation (only for callers that want them)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_calc_W_Y(int64_t N, const double* __restrict__ A,
+                                                  const double* __restrict__ B,
+                                                  const double* __restrict__ wgt,
+                                                  const double* __restrict__ Vinv,
+                                                  const int32_t* __restrict__ pt,
+                                                  double* __restrict__ W, double* __restrict__ Y) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  double a[14], b[6];
+#pragma unroll
+  for (int q = 0; q < 14; ++q) a[q] = A[14 * i + q];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) b[q] = B[6 * i + q];
+  double w00 = 1.0, w01 = 0.0, w10 = 0.0, w11 = 1.0;
+  if (wgt) {
+    w00 = wgt[4 * i]; w01 = wgt[4 * i + 1]; w10 = wgt[4 * i + 2]; w11 = wgt[4 * i + 3];
+  }
+  double vi[9];
+  const double* vp = Vinv + 9 * (int64_t)pt[i];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) vi[q] = vp[q];
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const double wa0 = a[r] * w00 + a[7 + r] * w10;
+    const double wa1 = a[r] * w01 + a[7 + r] * w11;
+    double wr[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) wr[q] = wa0 * b[q] + wa1 * b[3 + q];
+    if (W) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) W[21 * i + 3 * r + q] = wr[q];
+    }
+    if (Y) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) Y[21 * i + 3 * r + q] = wr[0] * vi[q] + wr[1] * vi[3 + q] + wr[2] * vi[6 + q];
+    }
+  }
+}
+
+__global__ void k_add_diagonal(double* S, int n7, double mu) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n7) S[(int64_t)i * n7 + i] += mu;
+}
+
+// ------------------------------------------------------------------------------------------
+// back-substitution: delta_b_i = V_i^-1 (eps_b_i - sum_a B_a^T w_a A_a delta_a[cam_a])
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_back_substitute(
+    const int32_t* __restrict__ grp_pt, const int32_t* __restrict__ pt_ptr,
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ slot_cam,
+    const double* __restrict__ A, const double* __restrict__ B, const double* __restrict__ wgt,
+    const double* __restrict__ Vinv, const double* __restrict__ eps_b, const double* __restrict__ da,
+    double* __restrict__ db, double* __restrict__ Xupd, double x_step) {
+  __shared__ double sV[kGroupSlots * 3];
+  __shared__ int sPtr[kGroupSlots + 1];
+  const int t = threadIdx.x;
+  const int p0 = grp_pt[blockIdx.x];
+  const int np = grp_pt[blockIdx.x + 1] - p0;
+  for (int i = t; i <= np; i += 256) sPtr[i] = pt_ptr[p0 + i];
+  __syncthreads();
+  const int s0 = sPtr[0];
+  const int ns = sPtr[np] - s0;
+  if (t < ns) {
+    const int64_t pos = perm[s0 + t];
+    const double* dj = da + 7 * (int64_t)slot_cam[s0 + t];
+    const double* ap = A + 14 * pos;
+    double h0 = 0.0, h1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      h0 += ap[q] * dj[q];
+      h1 += ap[7 + q] * dj[q];
+    }
+    double w00 = 1.0, w01 = 0.0, w10 = 0.0, w11 = 1.0;
+    if (wgt) {
+      const double* wp = wgt + 4 * pos;
+      w00 = wp[0]; w01 = wp[1]; w10 = wp[2]; w11 = wp[3];
+    }
+    const double k0 = w00 * h0 + w01 * h1, k1 = w10 * h0 + w11 * h1;
+    const double* b = B + 6 * pos;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) sV[3 * t + q] = b[q] * k0 + b[3 + q] * k1;
+  }
+  __syncthreads();
+  if (t < np) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int s = sPtr[t] - s0; s < sPtr[t + 1] - s0; ++s) {
+      a0 += sV[3 * s];
+      a1 += sV[3 * s + 1];
+      a2 += sV[3 * s + 2];
+    }
+    const int64_t p = p0 + t;
+    const double r0 = eps_b[3 * p] - a0, r1 = eps_b[3 * p + 1] - a1, r2 = eps_b[3 * p + 2] - a2;
+    const double* v = Vinv + 9 * p;
+    const double d0 = v[0] * r0 + v[1] * r1 + v[2] * r2;
+    const double d1 = v[3] * r0 + v[4] * r1 + v[5] * r2;
+    const double d2 = v[6] * r0 + v[7] * r1 + v[8] * r2;
+    db[3 * p] = d0; db[3 * p + 1] = d1; db[3 * p + 2] = d2;
+    if (Xupd) {
+      Xupd[3 * p] += x_step * d0;
+      Xupd[3 * p + 1] += x_step * d1;
+      Xupd[3 * p + 2] += x_step * d2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// camera update
+// ------------------------------------------------------------------------------------------
+__global__ void k_update_cameras(double* __restrict__ R, double* __restrict__ T, double* __restrict__ C,
+                                 double* __restrict__ P, const double* __restrict__ K, int k_stride,
+                                 const double* __restrict__ da, int m, int first, double q_step,
+                                 double c_step, int32_t* __restrict__ flags) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m || j < first) return;
+  double r[9], q[4];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r[i] = R[9 * (int64_t)j + i];
+  int f = 0;
+  if (!(fabs(det3(r) - 1.0) <= 1e-8 + 1e-5)) f |= SFM_BA_FLAG_DET_NOT_ONE;
+  rot_to_quat(r, q);
+  const double* d = da + 7 * (int64_t)j;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] += q_step * d[i];
+  const double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (!(nrm > 1e-8)) f |= SFM_BA_FLAG_ZERO_QUAT;
+  if (!isfinite(nrm)) f |= SFM_BA_FLAG_NONFINITE;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = q[i] / nrm;
+  quat_to_rot(q, r);
+  double c[3], t[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) c[i] = C[3 * (int64_t)j + i] + c_step * d[4 + i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) t[i] = -(r[3 * i] * c[0] + r[3 * i + 1] * c[1] + r[3 * i + 2] * c[2]);
+  // C = -R^T T as Frame.compute_projection_matrix recomputes it
+#pragma unroll
+  for (int i = 0; i < 3; ++i) c[i] = -(r[i] * t[0] + r[3 + i] * t[1] + r[6 + i] * t[2]);
+  const double* k = K + (int64_t)k_stride * j;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[9 * (int64_t)j + i] = r[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    T[3 * (int64_t)j + i] = t[i];
+    C[3 * (int64_t)j + i] = c[i];
+  }
+  if (P) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const double r0 = b < 3 ? r[b] : t[0], r1 = b < 3 ? r[3 + b] : t[1], r2 = b < 3 ? r[6 + b] : t[2];
+        P[12 * (int64_t)j + 4 * a + b] = k[3 * a] * r0 + k[3 * a + 1] * r1 + k[3 * a + 2] * r2;
+      }
+    }
+  }
+  if (flags) flags[j] = f;
+}
+
+// ------------------------------------------------------------------------------------------
+// cost: per-camera sum of squared residuals through the same per-camera work items
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kCamThreads) void k_cost_items(
+    const int32_t* __restrict__ item_beg, const int32_t* __restrict__ item_end,
+    const int32_t* __restrict__ cam_obs, const double* __restrict__ P, const double* __restrict__ X,
+    const int32_t* __restrict__ cam, const int32_t* __restrict__ pt, const double* __restrict__ xt,
+    double* __restrict__ part) {
+  __shared__ double red[kCamThreads];
+  const int t = threadIdx.x;
+  const int beg = item_beg[blockIdx.x], end = item_end[blockIdx.x];
+  double acc = 0.0;
+  for (int i = beg + t; i < end; i += kCamThreads) {
+    const int64_t pos = cam_obs ? cam_obs[i] : i;
+    const double* pm = P + 12 * (int64_t)cam[pos];
+    const double* x = X + 3 * (int64_t)pt[pos];
+    const double x0 = x[0], x1 = x[1], x2 = x[2];
+    const double h0 = pm[0] * x0 + pm[1] * x1 + pm[2] * x2 + pm[3];
+    const double h1 = pm[4] * x0 + pm[5] * x1 + pm[6] * x2 + pm[7];
+    const double h2 = pm[8] * x0 + pm[9] * x1 + pm[10] * x2 + pm[11];
+    const double2 xa = ld2(xt + 2 * pos);
+    const double e0 = xa.x - h0 / h2, e1 = xa.y - h1 / h2;
+    acc += e0 * e0 + e1 * e1;
+  }
+  red[t] = acc;
+  __syncthreads();
+  for (int s = kCamThreads / 2; s > 0; s >>= 1) {
+    if (t < s) red[t] += red[t + s];
+    __syncthreads();
+  }
+  if (t == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ void k_cost_camera_sum(const int32_t* __restrict__ cam_item_ptr, const double* __restrict__ part,
+                                  int m, double* __restrict__ ssq) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  double a = 0.0;
+  for (int it = cam_item_ptr[j]; it < cam_item_ptr[j + 1]; ++it) a += part[it];
+  ssq[j] = a;
+}
+
+__global__ __launch_bounds__(256) void k_cost_finish(const double* __restrict__ ssq, int m,
+                                                     double* __restrict__ cost) {
+  __shared__ double red[256];
+  const int t = threadIdx.x;
+  double a = 0.0;
+  for (int j = t; j < m; j += 256) a += sqrt(ssq[j]);
+  red[t] = a;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) red[t] += red[t + s];
+    __syncthreads();
+  }
+  if (t == 0) cost[0] = red[0] / (double)m;
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static inline int check_launch(const char* what) {
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_hip_error(err, what);
+    return SFM_BA_EHIP;
+  }
+  return SFM_BA_OK;
+}
+
+int launch_camera_prepare(const double* R, const double* C, const double* K, int k_stride, int m,
+                          double* blk, int32_t* flags, hipStream_t st) {
+  if (m <= 0) return SFM_BA_OK;
+  hipLaunchKernelGGL(k_camera_prepare, dim3((m + 63) / 64), dim3(64), 0, st, R, C, K, k_stride, m, blk, flags);
+  return check_launch("k_camera_prepare");
+}
+
+int launch_jacobian(const double* blk, const double* P, const double* X, const int32_t* cam,
+                    const int32_t* pt, int64_t N, double* A, double* B, double* xp, hipStream_t st) {
+  if (N <= 0) return SFM_BA_OK;
+  const int64_t grid = (N + 255) / 256;
+  hipLaunchKernelGGL(k_jacobian, dim3((unsigned)grid), dim3(256), 0, st, blk, P, X, cam, pt, N, A, B, xp);
+  return check_launch("k_jacobian");
+}
+
+int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, const double* xt,
+                    const double* xp, const double* w, double mu, double mu_u, double* S, double* e,
+                    double* U, double* eps_a, double* Vinv, double* eps_b, double* cam_red,
+                    void* ws, hipStream_t st) {
+  char* base = static_cast<char*>(ws);
+  double* g = reinterpret_cast<double*>(base + p->ws_g);
+  double* T = reinterpret_cast<double*>(base + p->ws_T);
+  double* campart = reinterpret_cast<double*>(base + p->ws_campart);
+  double* spart = reinterpret_cast<double*>(base + p->ws_spart);
+  if (p->n_groups > 0) {
+    hipLaunchKernelGGL(k_point, dim3(p->n_groups), dim3(256), 0, st, p->d_grp_pt, p->d_pt_ptr, p->d_perm,
+                       p->d_tp_ptr, B, xt, xp, w, mu, Vinv, eps_b, g, T);
+    int rc = check_launch("k_point");
+    if (rc) return rc;
+  }
+  if (p->n_items > 0) {
+    hipLaunchKernelGGL(k_camera_items, dim3(p->n_items), dim3(kCamThreads), 0, st, p->d_item_beg,
+                       p->d_item_end, p->d_cam_obs, A, xt, xp, w, g, campart);
+    int rc = check_launch("k_camera_items");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_camera_finish, dim3(p->m), dim3(64), 0, st, p->d_cam_item_ptr, campart, p->m, mu_u, S,
+                     e, U, eps_a, cam_red);
+  int rc = check_launch("k_camera_finish");
+  if (rc) return rc;
+  if (p->n_pair_items > 0 && S) {
+    hipLaunchKernelGGL(k_pair_blocks, dim3((p->n_pair_items + 3) / 4), dim3(256), 0, st, p->n_pair_items,
+                       p->d_pit_blk, p->d_pit_beg, p->d_pit_end, p->d_pit_part, p->d_blk_j, p->d_blk_k,
+                       p->d_entries, A, T, campart, p->d_cam_item_ptr, mu_u, p->m, S, spart);
+    rc = check_launch("k_pair_blocks");
+    if (rc) return rc;
+    if (p->n_multi > 0) {
+      hipLaunchKernelGGL(k_pair_finish, dim3(p->n_multi), dim3(64), 0, st, p->d_mb_blk, p->d_mb_part,
+                         p->d_mb_cnt, p->d_blk_j, p->d_blk_k, spart, campart, p->d_cam_item_ptr, mu_u, p->m, S);
+      rc = check_launch("k_pair_finish");
+      if (rc) return rc;
+    }
+  }
+  return SFM_BA_OK;
+}
+
+int launch_calc_W_Y(const sfm_ba_plan* p, const double* A, const double* B, const double* w,
+                    const double* Vinv, const int32_t* pt, double* W, double* Y, hipStream_t st) {
+  const int64_t N = p->n_obs;
+  if (N <= 0) return SFM_BA_OK;
+  hipLaunchKernelGGL(k_calc_W_Y, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, A, B, w, Vinv, pt, W, Y);
+  return check_launch("k_calc_W_Y");
+}
+
+int launch_add_diagonal(double* S, int n7, double mu, hipStream_t st) {
+  if (n7 <= 0) return SFM_BA_OK;
+  hipLaunchKernelGGL(k_add_diagonal, dim3((n7 + 255) / 256), dim3(256), 0, st, S, n7, mu);
+  return check_launch("k_add_diagonal");
+}
+
+int launch_back_substitute(const sfm_ba_plan* p, const double* A, const double* B, const double* w,
+                           const double* Vinv, const double* eps_b, const double* da, double* db,
+                           double* Xupd, double x_step, hipStream_t st) {
+  if (p->n_groups <= 0) return SFM_BA_OK;
+  hipLaunchKernelGGL(k_back_substitute, dim3(p->n_groups), dim3(256), 0, st, p->d_grp_pt, p->d_pt_ptr,
+                     p->d_perm, p->d_slot_cam, A, B, w, Vinv, eps_b, da, db, Xupd, x_step);
+  return check_launch("k_back_substitute");
+}
+
+int launch_update_cameras(double* R, double* T, double* C, double* P, const double* K, int k_stride,
+                          const double* da, int m, int first, double q_step, double c_step,
+                          int32_t* flags, hipStream_t st) {
+  if (m <= 0) return SFM_BA_OK;
+  hipLaunchKernelGGL(k_update_cameras, dim3((m + 63) / 64), dim3(64), 0, st, R, T, C, P, K, k_stride, da, m,
+                     first, q_step, c_step, flags);
+  return check_launch("k_update_cameras");
+}
+
+int launch_cost_partial(const sfm_ba_plan* p, const double* P, const double* X, const int32_t* cam,
+                        const int32_t* pt, const double* xt, double* ssq, void* ws, hipStream_t st) {
+  double* campart = reinterpret_cast<double*>(static_cast<char*>(ws) + p->ws_campart);
+  if (p->n_items > 0) {
+    hipLaunchKernelGGL(k_cost_items, dim3(p->n_items), dim3(kCamThreads), 0, st, p->d_item_beg, p->d_item_end,
+                       p->d_cam_obs, P, X, cam, pt, xt, campart);
+    int rc = check_launch("k_cost_items");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_cost_camera_sum, dim3((p->m + 255) / 256), dim3(256), 0, st, p->d_cam_item_ptr, campart,
+                     p->m, ssq);
+  return check_launch("k_cost_camera_sum");
+}
+
+int launch_cost_finish(const double* ssq, int m, double* cost, hipStream_t st) {
+  hipLaunchKernelGGL(k_cost_finish, dim3(1), dim3(256), 0, st, ssq, m, cost);
+  return check_launch("k_cost_finish");
+}
+
+}  // namespace sfmba

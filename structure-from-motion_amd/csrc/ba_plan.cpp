@@ -1,0 +1,277 @@
+// Visibility plan builder (host side): validates the (point, viewpoint) index lists the way the
+// reference's Indices class does and builds the index structures the kernels walk.
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ba_common.h"
+
+namespace sfmba {
+
+static thread_local std::string g_hip_error;
+
+void set_hip_error(hipError_t err, const char* what) {
+  g_hip_error = std::string(what) + ": " + hipGetErrorString(err);
+}
+
+const char* last_hip_error() { return g_hip_error.c_str(); }
+
+template <typename T>
+static int upload(const std::vector<T>& h, T** d, int64_t* bytes) {
+  *d = nullptr;
+  const size_t sz = std::max<size_t>(h.size(), 1) * sizeof(T);
+  SFMBA_HIP(hipMalloc(reinterpret_cast<void**>(d), sz));
+  if (!h.empty()) SFMBA_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  *bytes += (int64_t)sz;
+  return SFM_BA_OK;
+}
+
+static inline int64_t align256(int64_t v) { return (v + 255) & ~int64_t(255); }
+
+}  // namespace sfmba
+
+using namespace sfmba;
+
+extern "C" const char* sfm_ba_last_hip_error(void) { return sfmba::last_hip_error(); }
+
+extern "C" void sfm_ba_plan_destroy(sfm_ba_plan* p) {
+  if (!p) return;
+  void* ptrs[] = {p->d_pt_ptr,   p->d_perm,     p->d_slot_cam, p->d_tp_ptr,  p->d_grp_pt,  p->d_cam_obs,
+                  p->d_item_cam, p->d_item_beg, p->d_item_end, p->d_cam_item_ptr, p->d_blk_j, p->d_blk_k,
+                  p->d_entries,  p->d_pit_blk,  p->d_pit_beg,  p->d_pit_end, p->d_pit_part, p->d_mb_blk,
+                  p->d_mb_part,  p->d_mb_cnt};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  delete p;
+}
+
+extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx, int64_t N, int32_t m_hint,
+                                  int32_t n_hint, int check, sfm_ba_plan** out) {
+  if (!out) return SFM_BA_EINVAL;
+  *out = nullptr;
+  if (!cam_idx || !pt_idx || N <= 0 || N >= (int64_t(1) << 31)) return SFM_BA_EINVAL;
+  int32_t maxc = -1, maxp = -1;
+  for (int64_t i = 0; i < N; ++i) {
+    if (cam_idx[i] < 0 || pt_idx[i] < 0) return SFM_BA_EINVAL;
+    maxc = std::max(maxc, cam_idx[i]);
+    maxp = std::max(maxp, pt_idx[i]);
+  }
+  const int32_t m = m_hint > 0 ? m_hint : maxc + 1;
+  const int32_t n = n_hint > 0 ? n_hint : maxp + 1;
+  if (maxc >= m || maxp >= n) return SFM_BA_EINVAL;
+
+  // ---- sort observations by (point, camera): counting sort by camera, then stable by point ----
+  std::vector<int32_t> cam_cnt(m + 1, 0), pt_cnt(n + 1, 0);
+  bool cam_sorted = true;
+  for (int64_t i = 0; i < N; ++i) {
+    ++cam_cnt[cam_idx[i] + 1];
+    ++pt_cnt[pt_idx[i] + 1];
+    if (i > 0 && cam_idx[i] < cam_idx[i - 1]) cam_sorted = false;
+  }
+  if (check) {
+    if (m_hint <= 0)
+      for (int32_t j = 0; j < m; ++j)
+        if (cam_cnt[j + 1] == 0) return SFM_BA_EMISSING_VIEW;
+    if (n_hint <= 0)
+      for (int32_t i = 0; i < n; ++i)
+        if (pt_cnt[i + 1] == 0) return SFM_BA_EMISSING_POINT;
+  }
+  std::vector<int32_t> cam_ptr(m + 1, 0), pt_ptr(n + 1, 0);
+  for (int32_t j = 0; j < m; ++j) cam_ptr[j + 1] = cam_ptr[j] + cam_cnt[j + 1];
+  for (int32_t i = 0; i < n; ++i) pt_ptr[i + 1] = pt_ptr[i] + pt_cnt[i + 1];
+  std::vector<int32_t> by_cam(N);
+  {
+    std::vector<int32_t> fill(cam_ptr.begin(), cam_ptr.end() - 1);
+    for (int64_t i = 0; i < N; ++i) by_cam[fill[cam_idx[i]]++] = (int32_t)i;
+  }
+  std::vector<int32_t> perm(N), slot_cam(N);
+  {
+    std::vector<int32_t> fill(pt_ptr.begin(), pt_ptr.end() - 1);
+    for (int64_t q = 0; q < N; ++q) {
+      const int32_t i = by_cam[q];
+      const int32_t s = fill[pt_idx[i]]++;
+      perm[s] = i;
+      slot_cam[s] = cam_idx[i];
+    }
+  }
+  int32_t kmax = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    const int32_t k = pt_ptr[i + 1] - pt_ptr[i];
+    kmax = std::max(kmax, k);
+    if (check)
+      for (int32_t s = pt_ptr[i] + 1; s < pt_ptr[i + 1]; ++s)
+        if (slot_cam[s] == slot_cam[s - 1]) return SFM_BA_ENONUNIQUE;
+  }
+  if (kmax > SFM_BA_MAX_VIEWS || kmax > kGroupSlots) return SFM_BA_ETOOBIG;
+
+  sfm_ba_plan* p = new (std::nothrow) sfm_ba_plan();
+  if (!p) return SFM_BA_EINVAL;
+  p->m = m;
+  p->n = n;
+  p->n_obs = N;
+
+  // ---- per-point pair slots and workgroup ranges ----
+  std::vector<int32_t> tp_ptr(n + 1, 0), grp_pt;
+  int64_t pairs = 0;
+  {
+    int32_t in_group = 0;
+    grp_pt.push_back(0);
+    for (int32_t i = 0; i < n; ++i) {
+      const int32_t k = pt_ptr[i + 1] - pt_ptr[i];
+      if (in_group + k > kGroupSlots) {
+        grp_pt.push_back(i);
+        in_group = 0;
+      }
+      in_group += k;
+      tp_ptr[i] = (int32_t)pairs;
+      pairs += (int64_t)k * (k + 1) / 2;
+      if (pairs >= (int64_t(1) << 31)) {
+        delete p;
+        return SFM_BA_ETOOBIG;
+      }
+    }
+    tp_ptr[n] = (int32_t)pairs;
+    grp_pt.push_back(n);
+  }
+  p->n_groups = (int32_t)grp_pt.size() - 1;
+  p->n_pair_slots = pairs;
+
+  // ---- per-camera work items ----
+  std::vector<int32_t> item_cam, item_beg, item_end, cam_item_ptr(m + 1, 0);
+  for (int32_t j = 0; j < m; ++j) {
+    cam_item_ptr[j] = (int32_t)item_cam.size();
+    for (int32_t b = cam_ptr[j]; b < cam_ptr[j + 1]; b += kCamChunk) {
+      item_cam.push_back(j);
+      item_beg.push_back(b);
+      item_end.push_back(std::min(b + kCamChunk, cam_ptr[j + 1]));
+    }
+  }
+  cam_item_ptr[m] = (int32_t)item_cam.size();
+  p->n_items = (int32_t)item_cam.size();
+
+  // ---- camera-pair blocks (j <= k) and their entries, ordered by (j, k) then by point ----
+  std::vector<int32_t> blk_j, blk_k, blk_ptr;
+  std::vector<PairEntry> entries;
+  {
+    std::vector<int64_t> cnt((size_t)m * m, 0);
+    for (int32_t i = 0; i < n; ++i)
+      for (int32_t a = pt_ptr[i]; a < pt_ptr[i + 1]; ++a)
+        for (int32_t b = a; b < pt_ptr[i + 1]; ++b) ++cnt[(size_t)slot_cam[a] * m + slot_cam[b]];
+    int64_t total = 0;
+    for (int32_t j = 0; j < m; ++j)
+      for (int32_t k = j; k < m; ++k) {
+        const int64_t c = cnt[(size_t)j * m + k];
+        if (c == 0) {
+          cnt[(size_t)j * m + k] = -1;
+          continue;
+        }
+        blk_j.push_back(j);
+        blk_k.push_back(k);
+        blk_ptr.push_back((int32_t)total);
+        cnt[(size_t)j * m + k] = total;
+        total += c;
+      }
+    blk_ptr.push_back((int32_t)total);
+    entries.resize((size_t)total);
+    for (int32_t i = 0; i < n; ++i) {
+      const int32_t k = pt_ptr[i + 1] - pt_ptr[i];
+      for (int32_t a = 0; a < k; ++a)
+        for (int32_t b = a; b < k; ++b) {
+          const int32_t sa = pt_ptr[i] + a, sb = pt_ptr[i] + b;
+          int64_t& at = cnt[(size_t)slot_cam[sa] * m + slot_cam[sb]];
+          PairEntry en;
+          en.obs_a = perm[sa];
+          en.obs_b = perm[sb];
+          en.tslot = tp_ptr[i] + a * k - a * (a - 1) / 2 + (b - a);
+          en.pad = 0;
+          entries[(size_t)at++] = en;
+        }
+    }
+  }
+  p->n_blocks = (int32_t)blk_j.size();
+  p->n_entries = (int64_t)entries.size();
+
+  std::vector<int32_t> pit_blk, pit_beg, pit_end, pit_part, mb_blk, mb_part, mb_cnt;
+  int32_t n_parts = 0;
+  for (int32_t b = 0; b < p->n_blocks; ++b) {
+    const int32_t beg = blk_ptr[b], end = blk_ptr[b + 1];
+    const int32_t chunks = (end - beg + kPairChunk - 1) / kPairChunk;
+    if (chunks > 1) {
+      mb_blk.push_back(b);
+      mb_part.push_back(n_parts);
+      mb_cnt.push_back(chunks);
+    }
+    for (int32_t c = 0; c < chunks; ++c) {
+      pit_blk.push_back(b);
+      pit_beg.push_back(beg + c * kPairChunk);
+      pit_end.push_back(std::min(beg + (c + 1) * kPairChunk, end));
+      pit_part.push_back(chunks > 1 ? n_parts++ : -1);
+    }
+  }
+  p->n_pair_items = (int32_t)pit_blk.size();
+  p->n_parts = n_parts;
+  p->n_multi = (int32_t)mb_blk.size();
+
+  // ---- upload ----
+  int rc = SFM_BA_OK;
+  int64_t bytes = 0;
+  auto up = [&](auto& h, auto** d) {
+    if (rc == SFM_BA_OK) rc = upload(h, d, &bytes);
+  };
+  up(pt_ptr, &p->d_pt_ptr);
+  up(perm, &p->d_perm);
+  up(slot_cam, &p->d_slot_cam);
+  up(tp_ptr, &p->d_tp_ptr);
+  up(grp_pt, &p->d_grp_pt);
+  if (!cam_sorted) up(by_cam, &p->d_cam_obs);
+  up(item_cam, &p->d_item_cam);
+  up(item_beg, &p->d_item_beg);
+  up(item_end, &p->d_item_end);
+  up(cam_item_ptr, &p->d_cam_item_ptr);
+  up(blk_j, &p->d_blk_j);
+  up(blk_k, &p->d_blk_k);
+  up(entries, &p->d_entries);
+  up(pit_blk, &p->d_pit_blk);
+  up(pit_beg, &p->d_pit_beg);
+  up(pit_end, &p->d_pit_end);
+  up(pit_part, &p->d_pit_part);
+  up(mb_blk, &p->d_mb_blk);
+  up(mb_part, &p->d_mb_part);
+  up(mb_cnt, &p->d_mb_cnt);
+  if (rc != SFM_BA_OK) {
+    sfm_ba_plan_destroy(p);
+    return rc;
+  }
+  p->device_bytes = bytes;
+
+  // ---- workspace sections ----
+  int64_t off = 0;
+  p->ws_g = off;
+  off = align256(off + N * 2 * (int64_t)sizeof(double));
+  p->ws_T = off;
+  off = align256(off + pairs * 4 * (int64_t)sizeof(double));
+  p->ws_campart = off;
+  off = align256(off + (int64_t)std::max(p->n_items, 1) * SFM_BA_CAM_RED * (int64_t)sizeof(double));
+  p->ws_spart = off;
+  off = align256(off + (int64_t)std::max(n_parts, 1) * 49 * (int64_t)sizeof(double));
+  p->ws_total = off;
+  *out = p;
+  return SFM_BA_OK;
+}
+
+extern "C" int sfm_ba_plan_sizes(const sfm_ba_plan* p, int64_t what[8]) {
+  if (!p || !what) return SFM_BA_EINVAL;
+  what[0] = p->m;
+  what[1] = p->n;
+  what[2] = p->n_obs;
+  what[3] = p->n_blocks;
+  what[4] = p->n_entries;
+  what[5] = p->n_pair_slots;
+  what[6] = p->n_items;
+  what[7] = p->device_bytes;
+  return SFM_BA_OK;
+}
+
+extern "C" int64_t sfm_ba_plan_workspace_bytes(const sfm_ba_plan* p) { return p ? p->ws_total : 0; }

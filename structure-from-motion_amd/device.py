@@ -1,0 +1,282 @@
+"""Device-resident bundle-adjustment state and the Gauss-Newton loop over it.
+
+``DeviceProblem`` keeps cameras, points, observations, Jacobian blocks and the
+reduced camera system in HBM and drives the kernels of ``libsfm_ba.so`` through
+the C ABI; an iteration performs no host round trip except the scalar cost the
+reference's exit rule needs.  PyTorch is used for device memory, streams and
+``torch.distributed`` only.
+
+Loop being restated: ``optimize_using_BA`` of
+``/root/reference/src/bundle_adjustment.py:70-105`` (constants mu = 0.5, step
+scales 1.0 / 0.1 / 0.5, exit at cost <= 100 or 50 iterations).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+F64 = torch.float64
+I32 = torch.int32
+
+
+def _dev(device=None):
+    if not torch.cuda.is_available():
+        raise RuntimeError("no MI355X/ROCm device visible: this package computes on the GPU only")
+    return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Plan:
+    """Owner of a ``sfm_ba_plan`` handle (index structures of one visibility pattern)."""
+
+    def __init__(self, cam_idx, pt_idx, n_cams_hint=0, n_pts_hint=0, check=True):
+        lib = _lib.load()
+        cam = np.ascontiguousarray(cam_idx, dtype=np.int32)
+        pt = np.ascontiguousarray(pt_idx, dtype=np.int32)
+        assert cam.shape == pt.shape and cam.ndim == 1
+        _dev()
+        handle = C.c_void_p()
+        rc = lib.sfm_ba_plan_create(
+            cam.ctypes.data_as(C.c_void_p), pt.ctypes.data_as(C.c_void_p), cam.shape[0],
+            int(n_cams_hint), int(n_pts_hint), int(bool(check)), C.byref(handle))
+        _lib.check(rc)
+        self._lib = lib
+        self.handle = handle
+        sizes = (C.c_int64 * 8)()
+        _lib.check(lib.sfm_ba_plan_sizes(handle, sizes))
+        (self.m, self.n, self.n_obs, self.n_blocks, self.n_entries, self.n_pair_slots,
+         self.n_items, self.device_bytes) = [int(v) for v in sizes]
+        self.workspace_bytes = int(lib.sfm_ba_plan_workspace_bytes(handle))
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            self._lib.sfm_ba_plan_destroy(h)
+            self.handle = None
+
+
+class DeviceProblem:
+    """SoA BA problem in HBM.
+
+    Parameters (host numpy arrays): ``K`` (3,3) or (m,3,3); ``R`` (m,3,3); ``T`` (m,3);
+    ``X`` (n,3); ``cam_idx``/``pt_idx`` (N,) in caller order; ``x_true`` (N,2).
+    ``n_cams``: global camera count (a shard may not observe every camera).
+    ``group``: a ``torch.distributed`` process group when the points are sharded
+    over ranks; the camera system is then summed over the group every iteration.
+    """
+
+    MU = 0.5       # src/bundle_adjustment.py:79
+    Q_STEP = 1.0   # :88
+    C_STEP = 0.1   # :94
+    X_STEP = 0.5   # :100
+
+    def __init__(self, K, R, T, X, cam_idx, pt_idx, x_true, n_cams=None, group=None, check=True, device=None):
+        self.lib = _lib.load()
+        self.device = _dev(device)
+        self.group = group
+        self.world = 1
+        if group is not None:
+            import torch.distributed as dist
+
+            self.world = dist.get_world_size(group)
+        R = np.asarray(R, dtype=np.float64).reshape(-1, 3, 3)
+        self.m = int(R.shape[0]) if n_cams is None else int(n_cams)
+        assert R.shape[0] == self.m
+        X = np.asarray(X, dtype=np.float64).reshape(-1, 3)
+        self.n = int(X.shape[0])
+        cam_idx = np.ascontiguousarray(cam_idx, dtype=np.int32)
+        pt_idx = np.ascontiguousarray(pt_idx, dtype=np.int32)
+        self.N = int(cam_idx.shape[0])
+        sharded = self.world > 1
+        hinted = sharded or not check
+        self.plan = Plan(cam_idx, pt_idx, n_cams_hint=self.m if hinted else 0,
+                         n_pts_hint=self.n if hinted else 0, check=check)
+        if self.plan.m != self.m or self.plan.n != self.n:
+            # the reference's Indices asserts that every id up to the maximum occurs
+            raise AssertionError("index lists do not cover every camera / point")
+        d = self.device
+        K = np.asarray(K, dtype=np.float64)
+        if K.ndim == 2:
+            self.K = torch.from_numpy(K.reshape(1, 9).copy()).to(d)
+            self.k_stride = 0
+        else:
+            self.K = torch.from_numpy(K.reshape(-1, 9).copy()).to(d)
+            self.k_stride = 9
+            assert self.K.shape[0] == self.m
+        self.R = torch.from_numpy(R.reshape(-1, 9).copy()).to(d)
+        T = np.asarray(T, dtype=np.float64).reshape(-1, 3)
+        self.T = torch.from_numpy(T.copy()).to(d)
+        Cc = -np.einsum("mji,mj->mi", R, T)
+        self.C = torch.from_numpy(Cc).to(d)
+        Kb = np.broadcast_to(K, (self.m, 3, 3)) if K.ndim == 2 else K
+        P = Kb @ np.concatenate([R, T[:, :, None]], axis=2)
+        self.P = torch.from_numpy(np.ascontiguousarray(P).reshape(-1, 12)).to(d)
+        self.X = torch.from_numpy(X.copy()).to(d)
+        self.cam_idx = torch.from_numpy(cam_idx).to(d)
+        self.pt_idx = torch.from_numpy(pt_idx).to(d)
+        self.x_true = torch.from_numpy(np.ascontiguousarray(x_true, dtype=np.float64).reshape(-1, 2)).to(d)
+        self._alloc()
+
+    # -- state that the reference keeps on frames / map ---------------------------------------
+    def set_state(self, C=None, P=None):
+        """Override the derived camera centre / projection (frames may carry their own)."""
+        if C is not None:
+            self.C.copy_(torch.from_numpy(np.asarray(C, dtype=np.float64).reshape(-1, 3)))
+        if P is not None:
+            self.P.copy_(torch.from_numpy(np.asarray(P, dtype=np.float64).reshape(-1, 12)))
+
+    def _alloc(self):
+        d, m, n, N = self.device, self.m, self.n, self.N
+        n7 = 7 * m
+        self.n7 = n7
+        self.A = torch.empty((N, 14), dtype=F64, device=d)
+        self.B = torch.empty((N, 6), dtype=F64, device=d)
+        self.x_pred = torch.empty((N, 2), dtype=F64, device=d)
+        self.cam_blk = torch.empty((m, _lib.CAM_BLK), dtype=F64, device=d)
+        self.flags = torch.zeros((m,), dtype=I32, device=d)
+        self.upd_flags = torch.zeros((m,), dtype=I32, device=d)
+        # reduced system [(n7+1) x n7] followed by the per-camera squared-residual sums:
+        # one contiguous buffer so that a sharded run reduces it with a single collective
+        self.sys = torch.zeros(((n7 + 1) * n7 + m,), dtype=F64, device=d)
+        self.S = self.sys[: (n7 + 1) * n7].view(n7 + 1, n7)
+        self.ssq = self.sys[(n7 + 1) * n7:]
+        self.e = torch.empty((m, 7), dtype=F64, device=d)
+        self.U = torch.empty((m, 49), dtype=F64, device=d)
+        self.eps_a = torch.empty((m, 7), dtype=F64, device=d)
+        self.V_inv = torch.empty((n, 9), dtype=F64, device=d)
+        self.eps_b = torch.empty((n, 3), dtype=F64, device=d)
+        self.delta_a = torch.zeros((m, 7), dtype=F64, device=d)
+        self.delta_b = torch.zeros((n, 3), dtype=F64, device=d)
+        self.workspace = torch.empty((max(self.plan.workspace_bytes, 256) // 8,), dtype=F64, device=d)
+        self.chol_ws = torch.empty((int(self.lib.sfm_ba_cholesky_workspace_bytes(n7)) // 8 + 8,), dtype=F64, device=d)
+        self.info = torch.zeros((1,), dtype=I32, device=d)
+        self.cost_buf = torch.zeros((1,), dtype=F64, device=d)
+
+    # -- single stages ---------------------------------------------------------------------
+    def camera_prepare(self):
+        p = _lib.ptr
+        _lib.check(self.lib.sfm_ba_camera_prepare(p(self.R), p(self.C), p(self.K), self.k_stride, self.m,
+                                                  p(self.cam_blk), p(self.flags), _stream()))
+
+    def jacobian(self, want_pred=True):
+        p = _lib.ptr
+        _lib.check(self.lib.sfm_ba_jacobian(p(self.cam_blk), p(self.P), p(self.X), p(self.cam_idx), p(self.pt_idx),
+                                            self.N, p(self.A), p(self.B), p(self.x_pred) if want_pred else None,
+                                            _stream()))
+
+    def predict(self):
+        p = _lib.ptr
+        _lib.check(self.lib.sfm_ba_jacobian(p(self.cam_blk), p(self.P), p(self.X), p(self.cam_idx), p(self.pt_idx),
+                                            self.N, None, None, p(self.x_pred), _stream()))
+
+    def assemble(self, mu, weights=None, x_true=None, x_pred=None, A=None, B=None):
+        p = _lib.ptr
+        mu_u = mu if self.world == 1 else 0.0
+        n7 = self.n7
+        if self.plan.n_blocks < self.m * (self.m + 1) // 2:
+            # camera pairs without a shared point are not written by the kernels; the previous
+            # factorisation left fill-in there
+            self.sys[: n7 * n7].zero_()
+        _lib.check(self.lib.sfm_ba_schur_assemble(
+            self.plan.handle, p(self.A if A is None else A), p(self.B if B is None else B),
+            p(self.x_true if x_true is None else x_true), p(self.x_pred if x_pred is None else x_pred),
+            p(weights), float(mu), float(mu_u), p(self.S), p(self.e), p(self.U), p(self.eps_a),
+            p(self.V_inv), p(self.eps_b), None, p(self.workspace), _stream()))
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(self.sys[: (n7 + 1) * n7], group=self.group)
+            _lib.check(self.lib.sfm_ba_add_diagonal(p(self.S), n7, float(mu), _stream()))
+            self.e.copy_(self.S[n7].view(self.m, 7))
+
+    def solve(self):
+        p = _lib.ptr
+        _lib.check(self.lib.sfm_ba_solve_reduced(p(self.S), self.n7, p(self.delta_a), p(self.chol_ws),
+                                                 p(self.info), _stream()))
+
+    def back_substitute(self, weights=None, update_points=False, A=None, B=None):
+        p = _lib.ptr
+        _lib.check(self.lib.sfm_ba_back_substitute(
+            self.plan.handle, p(self.A if A is None else A), p(self.B if B is None else B), p(weights),
+            p(self.V_inv), p(self.eps_b), p(self.delta_a), p(self.delta_b),
+            p(self.X) if update_points else None, float(self.X_STEP), _stream()))
+
+    def update_cameras(self):
+        p = _lib.ptr
+        _lib.check(self.lib.sfm_ba_update_cameras(p(self.R), p(self.T), p(self.C), p(self.P), p(self.K),
+                                                  self.k_stride, p(self.delta_a), self.m, 1, float(self.Q_STEP),
+                                                  float(self.C_STEP), p(self.upd_flags), _stream()))
+
+    def cost_async(self):
+        """Enqueue the cost of the current state into ``cost_buf`` (no synchronisation)."""
+        p = _lib.ptr
+        _lib.check(self.lib.sfm_ba_cost_partial(self.plan.handle, p(self.P), p(self.X), p(self.cam_idx),
+                                                p(self.pt_idx), p(self.x_true), p(self.ssq), p(self.workspace),
+                                                _stream()))
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(self.ssq, group=self.group)
+        _lib.check(self.lib.sfm_ba_cost_finish(p(self.ssq), self.m, p(self.cost_buf), _stream()))
+
+    def cost(self) -> float:
+        self.cost_async()
+        return float(self.cost_buf.item())
+
+    # -- one Gauss-Newton iteration (src/bundle_adjustment.py:75-101) ---------------------------
+    def iterate_async(self, mu=None):
+        mu = self.MU if mu is None else mu
+        self.camera_prepare()
+        self.jacobian()
+        self.assemble(mu)
+        self.solve()
+        self.back_substitute(update_points=True)
+        self.update_cameras()
+        self.cost_async()
+
+    def check_flags(self):
+        """Raise what the reference would have raised during the iterations run so far."""
+        info = int(self.info.item())
+        if info != 0:
+            raise np.linalg.LinAlgError("Singular matrix")
+        f = int(torch.bitwise_or(self.flags, self.upd_flags).max().item()) if self.m else 0
+        if f & _lib.FLAG_DET_NOT_ONE:
+            raise AssertionError("Input matrix must have determinant 1 (be a rotation matrix)")
+        if f & _lib.FLAG_ZERO_QUAT:
+            raise ValueError("Cannot normalize quaternion with zero norm")
+        if f & _lib.FLAG_NONFINITE:
+            raise FloatingPointError("non-finite camera parameters")
+
+    def run(self, max_iter=50, threshold=100.0, min_iter=0, callback=None):
+        """The reference's loop: iterate while cost > threshold and fewer than
+        ``max_iter`` iterations were run.  Returns the per-iteration costs."""
+        costs = []
+        avg_error = 1e10
+        n_iter = 0
+        while (avg_error > threshold or n_iter < min_iter) and n_iter < max_iter:
+            self.iterate_async()
+            avg_error = float(self.cost_buf.item())
+            self.check_flags()
+            costs.append(avg_error)
+            if callback is not None:
+                callback(n_iter, avg_error)
+            n_iter += 1
+        return costs
+
+    # -- results back to the host --------------------------------------------------------------
+    def cameras(self):
+        R = self.R.cpu().numpy().reshape(-1, 3, 3)
+        T = self.T.cpu().numpy().reshape(-1, 3)
+        Cc = self.C.cpu().numpy().reshape(-1, 3)
+        P = self.P.cpu().numpy().reshape(-1, 3, 4)
+        return R, T, Cc, P
+
+    def points(self):
+        return self.X.cpu().numpy()
