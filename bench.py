@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Benchmark of the bundle-adjustment Gauss-Newton iteration on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--visibility MODE]
+
+A step is one full Gauss-Newton iteration of the reference's loop (per-camera records,
+Jacobian blocks and predictions, Schur assembly, reduced camera solve, back-substitution with
+the point update, camera update, cost) on synthetic data that is resident in HBM before the
+timed region starts.  With N > 1 (one process per GPU under torch.distributed.run) every rank
+holds the workload's point count (weak scaling: N x points, same cameras) and the camera
+system is all-reduced over RCCL each iteration.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
+FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector = matrix peak (datasheet)
+
+
+def algorithmic_bytes(N, n, m):
+    """Bytes per Gauss-Newton iteration a kernel group must move at minimum (fp64 values, int32
+    indices, A and B materialised as the reference's interface dictates)."""
+    return {
+        "jacobian": 184 * N + 24 * n + 128 * m,
+        "assembly": 200 * N + 96 * n + 392 * m * m + 560 * m,
+        "back_substitution": 168 * N + 120 * n + 56 * m,
+    }
+
+
+GROUPS = {
+    "jacobian": ["k_jacobian"],
+    "assembly": ["k_point", "k_camera_items", "k_camera_finish", "k_pair_blocks", "k_pair_finish"],
+    "back_substitution": ["k_back_substitute"],
+}
+
+
+def cpu_baseline(workload, visibility, seed, sample_points=60000, iters=2):
+    """The numpy oracle (a port of the reference's algorithm) on a bounded sample of the workload."""
+    import sfm_amd  # noqa: F401
+    from sfm_amd import synthetic
+    from oracle import ba_oracle as orc
+
+    p = synthetic.make_workload(workload, visibility=visibility, seed=seed, points=min(sample_points, synthetic.WORKLOADS[workload][1]))
+    R, T, X = p.R.copy(), p.T.copy(), p.X.copy()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        orc.gn_iteration_arrays(p.K, R, T, X, p.cam_idx, p.pt_idx, p.x_true)
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+
+        threads = max([d.get("num_threads", 1) for d in threadpool_info()] + [1])
+    except Exception:  # noqa: BLE001
+        threads = os.cpu_count() or 1
+    return {
+        "value": p.n_obs * iters / dt,
+        "unit": "obs/s",
+        "cores": int(threads),
+        "kind": "port",
+        "sample": f"{workload} restricted to its first {p.n} points ({p.n_obs} observations, {p.m} cameras), "
+                  f"{iters} Gauss-Newton iterations of the vectorised numpy oracle in {dt:.1f} s "
+                  f"(BLAS threads = cores; the Python-level work is single-threaded)",
+        "iters_per_sec": iters / dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c4_500x300k")
+    ap.add_argument("--visibility", default="banded", choices=["banded", "uniform"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import sfm_amd  # noqa: F401
+    from sfm_amd import _lib, synthetic
+    from sfm_amd.device import DeviceProblem
+    from sfm_amd.dist import local_problem, packed_system_elements
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    group = None
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        group = dist.group.WORLD
+
+    m, n_per_gpu, k = synthetic.WORKLOADS[args.workload]
+    n_total = n_per_gpu * world
+    full = synthetic.make_workload(args.workload, visibility=args.visibility, seed=args.seed, points=n_total)
+    N_total = full.n_obs
+    if world > 1:
+        prob_h, _ = local_problem(full, rank, world)
+    else:
+        prob_h = full
+    del full
+    prob = DeviceProblem(prob_h.K, prob_h.R, prob_h.T, prob_h.X, prob_h.cam_idx, prob_h.pt_idx, prob_h.x_true,
+                         n_cams=m, group=group, check=(world == 1))
+    N_loc, n_loc = prob.N, prob.n
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        prob.iterate_async()
+    barrier()
+    prob.check_flags()
+    _lib.profile_read()
+
+    # timed region: K iterations, per-kernel HIP events recorded on the launch stream
+    _lib.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        prob.iterate_async()
+    barrier()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    prof = _lib.profile_read()
+    final_cost = float(prob.cost_buf.item())
+    prob.check_flags()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # the same K iterations without the event records, for the cost of the instrumentation
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        prob.iterate_async()
+    barrier()
+    dt_plain = time.perf_counter() - t1
+
+    if rank == 0:
+        per_kernel = {name: {"ms_avg": ms / cnt, "launches_per_step": cnt / args.steps} for name, (ms, cnt) in prof.items()}
+        alg = algorithmic_bytes(N_loc, n_loc, m)
+        groups = {}
+        for g, names in GROUPS.items():
+            ms = sum(prof[nm][0] for nm in names if nm in prof) / args.steps
+            groups[g] = {"ms": ms, "bytes": alg[g], "GBps": alg[g] / (ms * 1e-3) / 1e9 if ms > 0 else None}
+        dominant = max(groups, key=lambda g: groups[g]["ms"])
+        roofline = {
+            "bound": "hbm",
+            "kernel": dominant + " (" + "+".join(GROUPS[dominant]) + ")",
+            "achieved": groups[dominant]["GBps"],
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": groups[dominant]["GBps"] / HBM_PEAK_GBS,
+            "traffic": None,
+            "groups": groups,
+        }
+        n7 = 7 * m
+        solve_ms = prof.get("solve_reduced", (0.0, 1))[0] / args.steps
+        solve = {
+            "bound": "fp64",
+            "flops": n7 ** 3 / 3.0 + 2.0 * n7 * n7,
+            "ms": solve_ms,
+            "achieved": (n7 ** 3 / 3.0 + 2.0 * n7 * n7) / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else None,
+            "peak": FP64_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+        }
+        out = {
+            "metric": "BA Gauss-Newton observations/sec (synthetic %d cams x %d pts)" % (m, n_total),
+            "value": N_total * args.steps / dt,
+            "unit": "obs/s",
+            "iters_per_sec": args.steps / dt,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_without_events": dt_plain / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {m} cameras x {n_total} points x {N_total} observations, "
+                            f"{args.visibility} visibility, seed {args.seed}, {n_per_gpu} points per GPU",
+                "cameras": m, "points": n_total, "observations": N_total, "visibility": args.visibility,
+                "parallelism": "1 gpu" if world == 1 else f"point-id sharding x{world}, all-reduce of "
+                               f"{packed_system_elements(m) * 8 / 1e6:.1f} MB per iteration",
+            },
+            "final_cost": final_cost,
+            "roofline": roofline,
+            "solve": solve,
+            "kernels": per_kernel,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.visibility, args.seed)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -199,6 +199,18 @@ int sfm_ba_cost_partial(const sfm_ba_plan* plan, const double* d_P, const double
                         double* d_cam_ssq, void* d_workspace, void* stream);
 int sfm_ba_cost_finish(const double* d_cam_ssq, int32_t m, double* d_cost, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Per-kernel timing (no counterpart in the reference, which has no profiler).  While enabled,
+ * every kernel launch made by the entry points above is bracketed by two HIP events recorded on
+ * the launch stream; sfm_ba_profile_read waits for them, adds the elapsed milliseconds and launch
+ * counts per kernel id into the two arrays of sfm_ba_profile_kernel_count() entries and forgets
+ * them.  "solve_reduced" is one id for the whole factor-and-solve sequence.
+ * ---------------------------------------------------------------------------------------- */
+int sfm_ba_profile_enable(int on);
+int sfm_ba_profile_kernel_count(void);
+const char* sfm_ba_profile_kernel_name(int id);
+int sfm_ba_profile_read(double* ms_total, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

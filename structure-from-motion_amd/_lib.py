@@ -40,6 +40,10 @@ SYMBOLS = {
     "sfm_ba_update_cameras": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _i32, _i32, _f64, _f64, _vp, _vp]),
     "sfm_ba_cost_partial": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_ba_cost_finish": (_int, [_vp, _i32, _vp, _vp]),
+    "sfm_ba_profile_enable": (_int, [_int]),
+    "sfm_ba_profile_kernel_count": (_int, []),
+    "sfm_ba_profile_kernel_name": (C.c_char_p, [_int]),
+    "sfm_ba_profile_read": (_int, [C.POINTER(_f64), C.POINTER(_i64)]),
 }
 
 _lib = None
@@ -93,3 +97,17 @@ def check(rc: int):
 def ptr(t):
     """Device pointer of a torch tensor (or None -> NULL)."""
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def profile_enable(on: bool):
+    check(load().sfm_ba_profile_enable(int(bool(on))))
+
+
+def profile_read():
+    """{kernel name: (total milliseconds, launches)} since the last read."""
+    lib = load()
+    k = lib.sfm_ba_profile_kernel_count()
+    ms = (C.c_double * k)()
+    cnt = (C.c_int64 * k)()
+    check(lib.sfm_ba_profile_read(ms, cnt))
+    return {lib.sfm_ba_profile_kernel_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(k) if cnt[i]}

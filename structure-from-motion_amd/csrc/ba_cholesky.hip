@@ -217,6 +217,7 @@ __global__ void k_copy_row(const double* __restrict__ src, double* __restrict__ 
 
 int launch_solve_reduced(double* S, int n, double* da, void* ws, int32_t* info, hipStream_t st) {
   if (n <= 0) return SFM_BA_OK;
+  ProfScope ps(KID_SOLVE, st);
   const int np = (n + NB - 1) / NB;
   double* invL = static_cast<double*>(ws);
   double* y = invL + (int64_t)np * NB * NB;

@@ -68,6 +68,26 @@ namespace sfmba {
 
 void set_hip_error(hipError_t err, const char* what);
 
+// per-kernel timing (ba_profile.cpp): a ProfScope around a launch records two events on the
+// launch stream while profiling is enabled, and costs one branch otherwise
+enum KernelId {
+  KID_CAMERA_PREPARE = 0, KID_JACOBIAN, KID_POINT, KID_CAMERA_ITEMS, KID_CAMERA_FINISH, KID_PAIR_BLOCKS,
+  KID_PAIR_FINISH, KID_SOLVE, KID_BACK, KID_UPDATE, KID_COST_ITEMS, KID_COST_FINISH, KID_CALC_W_Y, KID_COUNT
+};
+bool profiling_enabled();
+class ProfScope {
+ public:
+  ProfScope(int id, hipStream_t st);
+  ~ProfScope();
+  ProfScope(const ProfScope&) = delete;
+  ProfScope& operator=(const ProfScope&) = delete;
+
+ private:
+  int id_;
+  hipStream_t st_;
+  void* start_;
+};
+
 #define SFMBA_HIP(call)                         \
   do {                                          \
     hipError_t err__ = (call);                  \

@@ -748,7 +748,10 @@ static inline int check_launch(const char* what) {
 int launch_camera_prepare(const double* R, const double* C, const double* K, int k_stride, int m,
                           double* blk, int32_t* flags, hipStream_t st) {
   if (m <= 0) return SFM_BA_OK;
-  hipLaunchKernelGGL(k_camera_prepare, dim3((m + 63) / 64), dim3(64), 0, st, R, C, K, k_stride, m, blk, flags);
+  {
+    ProfScope ps(KID_CAMERA_PREPARE, st);
+    hipLaunchKernelGGL(k_camera_prepare, dim3((m + 63) / 64), dim3(64), 0, st, R, C, K, k_stride, m, blk, flags);
+  }
   return check_launch("k_camera_prepare");
 }
 
@@ -756,7 +759,10 @@ int launch_jacobian(const double* blk, const double* P, const double* X, const i
                     const int32_t* pt, int64_t N, double* A, double* B, double* xp, hipStream_t st) {
   if (N <= 0) return SFM_BA_OK;
   const int64_t grid = (N + 255) / 256;
-  hipLaunchKernelGGL(k_jacobian, dim3((unsigned)grid), dim3(256), 0, st, blk, P, X, cam, pt, N, A, B, xp);
+  {
+    ProfScope ps(KID_JACOBIAN, st);
+    hipLaunchKernelGGL(k_jacobian, dim3((unsigned)grid), dim3(256), 0, st, blk, P, X, cam, pt, N, A, B, xp);
+  }
   return check_launch("k_jacobian");
 }
 
@@ -770,30 +776,45 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
   double* campart = reinterpret_cast<double*>(base + p->ws_campart);
   double* spart = reinterpret_cast<double*>(base + p->ws_spart);
   if (p->n_groups > 0) {
+    {
+    ProfScope ps(KID_POINT, st);
     hipLaunchKernelGGL(k_point, dim3(p->n_groups), dim3(256), 0, st, p->d_grp_pt, p->d_pt_ptr, p->d_perm,
                        p->d_tp_ptr, B, xt, xp, w, mu, Vinv, eps_b, g, T);
+  }
     int rc = check_launch("k_point");
     if (rc) return rc;
   }
   if (p->n_items > 0) {
+    {
+    ProfScope ps(KID_CAMERA_ITEMS, st);
     hipLaunchKernelGGL(k_camera_items, dim3(p->n_items), dim3(kCamThreads), 0, st, p->d_item_beg,
                        p->d_item_end, p->d_cam_obs, A, xt, xp, w, g, campart);
+  }
     int rc = check_launch("k_camera_items");
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(k_camera_finish, dim3(p->m), dim3(64), 0, st, p->d_cam_item_ptr, campart, p->m, mu_u, S,
+  {
+    ProfScope ps(KID_CAMERA_FINISH, st);
+    hipLaunchKernelGGL(k_camera_finish, dim3(p->m), dim3(64), 0, st, p->d_cam_item_ptr, campart, p->m, mu_u, S,
                      e, U, eps_a, cam_red);
+  }
   int rc = check_launch("k_camera_finish");
   if (rc) return rc;
   if (p->n_pair_items > 0 && S) {
+    {
+    ProfScope ps(KID_PAIR_BLOCKS, st);
     hipLaunchKernelGGL(k_pair_blocks, dim3((p->n_pair_items + 3) / 4), dim3(256), 0, st, p->n_pair_items,
                        p->d_pit_blk, p->d_pit_beg, p->d_pit_end, p->d_pit_part, p->d_blk_j, p->d_blk_k,
                        p->d_entries, A, T, campart, p->d_cam_item_ptr, mu_u, p->m, S, spart);
+  }
     rc = check_launch("k_pair_blocks");
     if (rc) return rc;
     if (p->n_multi > 0) {
-      hipLaunchKernelGGL(k_pair_finish, dim3(p->n_multi), dim3(64), 0, st, p->d_mb_blk, p->d_mb_part,
+      {
+    ProfScope ps(KID_PAIR_FINISH, st);
+    hipLaunchKernelGGL(k_pair_finish, dim3(p->n_multi), dim3(64), 0, st, p->d_mb_blk, p->d_mb_part,
                          p->d_mb_cnt, p->d_blk_j, p->d_blk_k, spart, campart, p->d_cam_item_ptr, mu_u, p->m, S);
+  }
       rc = check_launch("k_pair_finish");
       if (rc) return rc;
     }
@@ -805,7 +826,10 @@ int launch_calc_W_Y(const sfm_ba_plan* p, const double* A, const double* B, cons
                     const double* Vinv, const int32_t* pt, double* W, double* Y, hipStream_t st) {
   const int64_t N = p->n_obs;
   if (N <= 0) return SFM_BA_OK;
-  hipLaunchKernelGGL(k_calc_W_Y, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, A, B, w, Vinv, pt, W, Y);
+  {
+    ProfScope ps(KID_CALC_W_Y, st);
+    hipLaunchKernelGGL(k_calc_W_Y, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, A, B, w, Vinv, pt, W, Y);
+  }
   return check_launch("k_calc_W_Y");
 }
 
@@ -819,8 +843,11 @@ int launch_back_substitute(const sfm_ba_plan* p, const double* A, const double* 
                            const double* Vinv, const double* eps_b, const double* da, double* db,
                            double* Xupd, double x_step, hipStream_t st) {
   if (p->n_groups <= 0) return SFM_BA_OK;
-  hipLaunchKernelGGL(k_back_substitute, dim3(p->n_groups), dim3(256), 0, st, p->d_grp_pt, p->d_pt_ptr,
+  {
+    ProfScope ps(KID_BACK, st);
+    hipLaunchKernelGGL(k_back_substitute, dim3(p->n_groups), dim3(256), 0, st, p->d_grp_pt, p->d_pt_ptr,
                      p->d_perm, p->d_slot_cam, A, B, w, Vinv, eps_b, da, db, Xupd, x_step);
+  }
   return check_launch("k_back_substitute");
 }
 
@@ -828,8 +855,11 @@ int launch_update_cameras(double* R, double* T, double* C, double* P, const doub
                           const double* da, int m, int first, double q_step, double c_step,
                           int32_t* flags, hipStream_t st) {
   if (m <= 0) return SFM_BA_OK;
-  hipLaunchKernelGGL(k_update_cameras, dim3((m + 63) / 64), dim3(64), 0, st, R, T, C, P, K, k_stride, da, m,
+  {
+    ProfScope ps(KID_UPDATE, st);
+    hipLaunchKernelGGL(k_update_cameras, dim3((m + 63) / 64), dim3(64), 0, st, R, T, C, P, K, k_stride, da, m,
                      first, q_step, c_step, flags);
+  }
   return check_launch("k_update_cameras");
 }
 
@@ -837,8 +867,11 @@ int launch_cost_partial(const sfm_ba_plan* p, const double* P, const double* X, 
                         const int32_t* pt, const double* xt, double* ssq, void* ws, hipStream_t st) {
   double* campart = reinterpret_cast<double*>(static_cast<char*>(ws) + p->ws_campart);
   if (p->n_items > 0) {
+    {
+    ProfScope ps(KID_COST_ITEMS, st);
     hipLaunchKernelGGL(k_cost_items, dim3(p->n_items), dim3(kCamThreads), 0, st, p->d_item_beg, p->d_item_end,
                        p->d_cam_obs, P, X, cam, pt, xt, campart);
+  }
     int rc = check_launch("k_cost_items");
     if (rc) return rc;
   }
@@ -848,7 +881,10 @@ int launch_cost_partial(const sfm_ba_plan* p, const double* P, const double* X, 
 }
 
 int launch_cost_finish(const double* ssq, int m, double* cost, hipStream_t st) {
-  hipLaunchKernelGGL(k_cost_finish, dim3(1), dim3(256), 0, st, ssq, m, cost);
+  {
+    ProfScope ps(KID_COST_FINISH, st);
+    hipLaunchKernelGGL(k_cost_finish, dim3(1), dim3(256), 0, st, ssq, m, cost);
+  }
   return check_launch("k_cost_finish");
 }
 
