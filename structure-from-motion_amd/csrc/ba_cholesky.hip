@@ -3,16 +3,27 @@
 // side carried as row n of the same buffer, so that the forward substitution L y = e happens as
 // part of the panel solves.  Then a blocked backward substitution L^T x = y.
 //
-// Per panel of NB columns:
-//   k_chol_diag   : one workgroup factors the NB x NB diagonal block in LDS and inverts its factor
-//   k_chol_panel  : rows below the block (and the right-hand-side row) times inv(L_kk)^T
-//   k_chol_update : trailing lower-triangle tiles  A_ij -= P_i P_j^T
+// Per panel of NB = 64 columns:
+//   k_chol_diag   : one workgroup factors the 64 x 64 diagonal block and inverts its factor.  The
+//                   block is handled as 4 x 4 sub-blocks of 16: a 16 x 16 sub-block is factored and
+//                   inverted by one wave in registers (row per lane, cross-lane reads instead of
+//                   LDS round trips and workgroup barriers); the rest is small LDS products.
+//   k_chol_panel  : rows below the block (and the right-hand-side row) times inv(L_kk)^T   [MFMA]
+//   k_chol_update : trailing lower-triangle tiles  A_ij -= P_i P_j^T                        [MFMA]
+// The two product kernels use v_mfma_f64_16x16x4_f64: a 64 x 64 output tile per workgroup, one
+// 32 x 32 quadrant (2 x 2 MFMA tiles) per wave, operands staged in LDS with a row stride of 66
+// doubles (conflict-free for the one-double-per-lane operand reads).
+#include <cstdlib>
+
 #include "ba_common.h"
 
 namespace sfmba {
 
-constexpr int NB = 64;       // panel width = tile edge
-constexpr int LDT = NB + 1;  // padded LDS row
+constexpr int NB = 64;   // panel width = tile edge
+constexpr int LDT = 66;  // LDS row stride in doubles
+constexpr int SB = 16;   // sub-block edge inside the diagonal kernel
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
 
 // workspace: [n_panels][NB*NB] inverse diagonal factors, then y[n] (running right-hand side of the
 // backward substitution)
@@ -21,67 +32,191 @@ int64_t cholesky_workspace_bytes(int n) {
   return (np * NB * NB + (int64_t)np * NB + 64) * (int64_t)sizeof(double);
 }
 
+// value of `v` in lane `lane` (wave-uniform constant lane index)
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Factor the 16 x 16 lower-triangular-stored block whose row r sits in lane r (a[0..15], entries
+// above the diagonal ignored) and invert the factor.  On return a[] holds row r of L and x[] row
+// r of L^-1 (zeros above the diagonal).  Returns the index+1 of the first non-positive pivot or 0.
+__device__ __forceinline__ int factor16(double (&a)[SB], double (&x)[SB], int r) {
+  int bad = 0;
+  double inv_diag = 0.0;  // 1 / L[r][r] of this lane's row
+#pragma unroll
+  for (int j = 0; j < SB; ++j) {
+    const double d = lane_bcast(a[j], j);
+    if (!(d > 0.0) && bad == 0) bad = j + 1;
+    const double rs = rsqrt(d);
+    const double l = (r == j) ? d * rs : a[j] * rs;
+    if (r == j) inv_diag = rs;
+    a[j] = l;
+#pragma unroll
+    for (int c = j + 1; c < SB; ++c) {
+      const double lc = lane_bcast(l, c);
+      a[c] -= l * lc;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < SB; ++c)
+    if (c > r) a[c] = 0.0;
+  // inverse by rows: X[q][c] final once rows < q were broadcast; lane r accumulates
+  // acc[c] = sum_{q<r} L[r][q] X[q][c]
+  double acc[SB];
+#pragma unroll
+  for (int c = 0; c < SB; ++c) {
+    acc[c] = 0.0;
+    x[c] = 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < SB; ++q) {
+    // finalise row q in lane q
+    if (r == q) {
+#pragma unroll
+      for (int c = 0; c < SB; ++c)
+        if (c < q) x[c] = -inv_diag * acc[c];
+      x[q] = inv_diag;
+    }
+#pragma unroll
+    for (int c = 0; c <= q; ++c) {
+      const double xq = lane_bcast(x[c], q);
+      acc[c] += a[q] * xq;  // a[q] = L[r][q], zero for q > r
+    }
+  }
+  return bad;
+}
+
 __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ S, int n, int k0, int nb,
-                                                   double* __restrict__ invL, int32_t* __restrict__ info) {
+                                                   double* __restrict__ invL, int32_t* __restrict__ info, int dbg) {
   __shared__ double L[NB * LDT];
   __shared__ double X[NB * LDT];
-  __shared__ double piv[NB];
+  __shared__ double M[NB * LDT];
   const int t = threadIdx.x;
-  const int tr = t >> 4, tc = t & 15;
-  for (int idx = t; idx < NB * NB; idx += 256) {
-    const int r = idx / NB, c = idx % NB;
-    double v = 0.0;
-    if (r < nb && c <= r) v = S[(int64_t)(k0 + r) * n + k0 + c];
-    L[r * LDT + c] = v;
+  const int lane = t & 63, wave = t >> 6;
+  {
+    // all 16 loads of a lane are issued before the first LDS store (one memory latency, not 16)
+    double v[NB * NB / 256];
+#pragma unroll
+    for (int it = 0; it < NB * NB / 256; ++it) {
+      const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
+      v[it] = (r == c) ? 1.0 : 0.0;  // identity padding keeps the padded factor well defined
+      if (r < nb && c < nb) v[it] = (c <= r) ? S[(int64_t)(k0 + r) * n + k0 + c] : 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < NB * NB / 256; ++it) {
+      const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
+      L[r * LDT + c] = v[it];
+      X[r * LDT + c] = 0.0;
+    }
   }
-  for (int j = 0; j < nb; ++j) {
+  for (int kk = 0; kk < NB / SB; ++kk) {
+    const int o = kk * SB;
     __syncthreads();
-    const double d = L[j * LDT + j];
-    if (t == 0) {
-      piv[j] = d;
-      if (!(d > 0.0) && atomicCAS(info, 0, k0 + j + 1) == 0) {
+    // (1) factor + invert the 16 x 16 diagonal sub-block in registers of wave 0
+    if (wave == 0) {
+      double a[SB], x[SB];
+      const int r = lane & 15;
+#pragma unroll
+      for (int c = 0; c < SB; ++c) a[c] = L[(o + r) * LDT + o + c];
+      int bad = 0;
+      if (!(dbg & 1)) bad = factor16(a, x, r);
+      else {
+#pragma unroll
+        for (int c = 0; c < SB; ++c) x[c] = a[c];
+      }
+      if (lane < SB) {
+#pragma unroll
+        for (int c = 0; c < SB; ++c) {
+          L[(o + r) * LDT + o + c] = a[c];
+          X[(o + r) * LDT + o + c] = x[c];
+        }
+        if (bad && lane == 0 && o + bad <= nb) atomicCAS(info, 0, k0 + o + bad);
       }
     }
-    const double id = 1.0 / d;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int r = tr + 16 * a;
-      if (r <= j || r >= nb) continue;
-      const double lrj = L[r * LDT + j] * id;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int c = tc + 16 * b;
-        if (c > j && c <= r) L[r * LDT + c] -= lrj * L[c * LDT + j];
-      }
-    }
-  }
-  __syncthreads();
-  // scale the columns: L[r][j] = numerators / sqrt(pivot)
-  for (int idx = t; idx < NB * NB; idx += 256) {
-    const int r = idx / NB, c = idx % NB;
-    if (r < nb && c <= r) {
-      const double s = sqrt(piv[c]);
-      const double v = (r == c) ? s : L[r * LDT + c] / s;
-      L[r * LDT + c] = v;
-      S[(int64_t)(k0 + r) * n + k0 + c] = v;
-    }
-  }
-  __syncthreads();
-  // inverse of the lower-triangular factor, one lane per column
-  if (t < NB) {
-    const int c = t;
-    for (int r = 0; r < NB; ++r) X[r * LDT + c] = 0.0;
-    if (c < nb) {
-      X[c * LDT + c] = 1.0 / L[c * LDT + c];
-      for (int r = c + 1; r < nb; ++r) {
+    __syncthreads();
+    const int below = NB - o - SB;  // rows under the sub-block
+    if (below > 0 && !(dbg & 2)) {
+      // (2) rows below: Bnew = B * Xd^T  (Xd = inverse of the sub-block's factor)
+      for (int idx = t; idx < below * SB; idx += 256) {
+        const int r = o + SB + idx / SB, c = idx % SB;
         double s = 0.0;
-        for (int q = c; q < r; ++q) s += L[r * LDT + q] * X[q * LDT + c];
-        X[r * LDT + c] = -s / L[r * LDT + r];
+#pragma unroll
+        for (int q = 0; q < SB; ++q) s += L[r * LDT + o + q] * X[(o + c) * LDT + o + q];
+        M[r * LDT + c] = s;
+      }
+      __syncthreads();
+      for (int idx = t; idx < below * SB; idx += 256) {
+        const int r = o + SB + idx / SB, c = idx % SB;
+        L[r * LDT + o + c] = M[r * LDT + c];
+      }
+      // (3) trailing sub-blocks: C -= Bnew Bnew^T (lower part), reading Bnew from M
+      for (int idx = t; idx < below * below; idx += 256) {
+        const int rr = idx / below, cc = idx % below;
+        if (cc > rr) continue;
+        const int r = o + SB + rr, c = o + SB + cc;
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < SB; ++q) s += M[r * LDT + q] * M[c * LDT + q];
+        L[r * LDT + c] -= s;
       }
     }
   }
   __syncthreads();
-  for (int idx = t; idx < NB * NB; idx += 256) invL[idx] = X[(idx / NB) * LDT + (idx % NB)];
+  // 64 x 64 inverse from the 16 x 16 blocks: X_ij = -X_ii sum_{q=j}^{i-1} L_iq X_qj, by distance i-j
+  for (int dist = 1; dist < NB / SB && !(dbg & 4); ++dist) {
+    const int nblk = NB / SB - dist;
+    for (int idx = t; idx < nblk * SB * SB; idx += 256) {
+      const int b = idx / (SB * SB), rr = (idx / SB) % SB, cc = idx % SB;
+      const int bi = b + dist, bj = b;
+      double s = 0.0;
+      for (int q = bj * SB; q < bi * SB; ++q) s += L[(bi * SB + rr) * LDT + q] * X[q * LDT + bj * SB + cc];
+      M[(bi * SB + rr) * LDT + bj * SB + cc] = s;
+    }
+    __syncthreads();
+    for (int idx = t; idx < nblk * SB * SB; idx += 256) {
+      const int b = idx / (SB * SB), rr = (idx / SB) % SB, cc = idx % SB;
+      const int bi = b + dist, bj = b;
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < SB; ++q) s += X[(bi * SB + rr) * LDT + bi * SB + q] * M[(bi * SB + q) * LDT + bj * SB + cc];
+      X[(bi * SB + rr) * LDT + bj * SB + cc] = -s;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int it = 0; it < NB * NB / 256; ++it) {
+    const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
+    const bool in = r < nb && c < nb;
+    invL[idx] = in ? X[r * LDT + c] : 0.0;
+    if (in && c <= r) S[(int64_t)(k0 + r) * n + k0 + c] = L[r * LDT + c];
+  }
+}
+
+// 64 x 64 x 64 product on the matrix cores: acc (2 x 2 MFMA tiles of this wave's 32 x 32 quadrant)
+// += sign * Pa[rows] Pb[cols]^T with both operands stored [row][k] in LDS.
+__device__ __forceinline__ void mfma_quadrant(const double* __restrict__ Pa, const double* __restrict__ Pb,
+                                              int wr, int wc, int lane, bool negate, d4_t (&acc)[2][2]) {
+  const int lr = lane & 15, lk = lane >> 4;
+  const double* pa0 = Pa + (wr * 32 + lr) * LDT + lk;
+  const double* pa1 = pa0 + 16 * LDT;
+  const double* pb0 = Pb + (wc * 32 + lr) * LDT + lk;
+  const double* pb1 = pb0 + 16 * LDT;
+#pragma unroll 4
+  for (int kk = 0; kk < NB; kk += 4) {
+    double a0 = pa0[kk], a1 = pa1[kk];
+    const double b0 = pb0[kk], b1 = pb1[kk];
+    if (negate) {
+      a0 = -a0;
+      a1 = -a1;
+    }
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  }
 }
 
 // P = A_tile * invL^T for the 64-row tiles below the diagonal block; rows up to and including n
@@ -92,48 +227,47 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int 
   __shared__ double It[NB * LDT];
   const int t = threadIdx.x;
   const int row0 = k0 + nb + blockIdx.x * NB;
-  for (int idx = t; idx < NB * NB; idx += 256) {
-    const int r = idx / NB, c = idx % NB;
-    double v = 0.0;
-    if (row0 + r <= n && c < nb) v = S[(int64_t)(row0 + r) * n + k0 + c];
-    At[r * LDT + c] = v;
-    It[r * LDT + c] = invL[idx];
-  }
-  __syncthreads();
-  const int tr = t >> 4, tc = t & 15;
-  double acc[4][4];
+  {
+    double va[NB * NB / 256], vi[NB * NB / 256];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+    for (int it = 0; it < NB * NB / 256; ++it) {
+      const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
+      va[it] = (row0 + r <= n && c < nb) ? S[(int64_t)(row0 + r) * n + k0 + c] : 0.0;
+      vi[it] = invL[idx];
+    }
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-  for (int q = 0; q < nb; ++q) {
-    double av[4], iv[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) av[a] = At[(tr + 16 * a) * LDT + q];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) iv[b] = It[(tc + 16 * b) * LDT + q];  // invL[c][q]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] += av[a] * iv[b];
-  }
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int r = row0 + tr + 16 * a;
-    if (r > n) continue;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int c = tc + 16 * b;
-      if (c < nb) S[(int64_t)r * n + k0 + c] = acc[a][b];
+    for (int it = 0; it < NB * NB / 256; ++it) {
+      const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
+      At[r * LDT + c] = va[it];
+      It[r * LDT + c] = vi[it];
     }
   }
+  __syncthreads();
+  const int lane = t & 63, wave = t >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  d4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+  mfma_quadrant(At, It, wr, wc, lane, false, acc);
+  // result element (i, j, reg): row = 32 wr + 16 i + (lane >> 4) + 4 reg, col = 32 wc + 16 j + (lane & 15)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = row0 + wr * 32 + i * 16 + (lane >> 4) + 4 * g;
+        const int c = wc * 32 + j * 16 + (lane & 15);
+        if (r <= n && c < nb) S[(int64_t)r * n + k0 + c] = acc[i][j][g];
+      }
 }
 
 // trailing update A_ij -= P_i P_j^T over lower-triangle tiles (ti >= tj); grid.x enumerates them
 __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int n, int k0, int nb, int ntile) {
   __shared__ double Pi[NB * LDT];
   __shared__ double Pj[NB * LDT];
-  // decode (ti, tj), ti >= tj, from the linear index
   const int lin = blockIdx.x;
   int ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
   while ((int64_t)(ti + 1) * (ti + 2) / 2 <= lin) ++ti;
@@ -143,44 +277,47 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
   const int t = threadIdx.x;
   const int base = k0 + nb;
   const int row0 = base + ti * NB, col0 = base + tj * NB;
-  for (int idx = t; idx < NB * NB; idx += 256) {
-    const int r = idx / NB, c = idx % NB;
-    double vi = 0.0, vj = 0.0;
-    if (c < nb) {
-      if (row0 + r <= n) vi = S[(int64_t)(row0 + r) * n + k0 + c];
-      if (col0 + r < n) vj = S[(int64_t)(col0 + r) * n + k0 + c];
+  const int lane = t & 63, wave = t >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  // the tile's current values go straight into the accumulators
+  d4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = row0 + wr * 32 + i * 16 + (lane >> 4) + 4 * g;
+        const int c = col0 + wc * 32 + j * 16 + (lane & 15);
+        acc[i][j][g] = (r <= n && c < n && c <= r) ? S[(int64_t)r * n + c] : 0.0;
+      }
+  {
+    double vi[NB * NB / 256], vj[NB * NB / 256];
+#pragma unroll
+    for (int it = 0; it < NB * NB / 256; ++it) {
+      const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
+      vi[it] = (c < nb && row0 + r <= n) ? S[(int64_t)(row0 + r) * n + k0 + c] : 0.0;
+      vj[it] = (c < nb && col0 + r < n) ? S[(int64_t)(col0 + r) * n + k0 + c] : 0.0;
     }
-    Pi[r * LDT + c] = vi;
-    Pj[r * LDT + c] = vj;
+#pragma unroll
+    for (int it = 0; it < NB * NB / 256; ++it) {
+      const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
+      Pi[r * LDT + c] = vi[it];
+      Pj[r * LDT + c] = vj[it];
+    }
   }
   __syncthreads();
-  const int tr = t >> 4, tc = t & 15;
-  double acc[4][4];
+  mfma_quadrant(Pi, Pj, wr, wc, lane, true, acc);
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-  for (int q = 0; q < nb; ++q) {
-    double av[4], bv[4];
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int a = 0; a < 4; ++a) av[a] = Pi[(tr + 16 * a) * LDT + q];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) bv[b] = Pj[(tc + 16 * b) * LDT + q];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] += av[a] * bv[b];
-  }
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int r = row0 + tr + 16 * a;
-    if (r > n) continue;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int c = col0 + tc + 16 * b;
-      if (c < n && c <= r) S[(int64_t)r * n + c] -= acc[a][b];
-    }
-  }
+      for (int g = 0; g < 4; ++g) {
+        const int r = row0 + wr * 32 + i * 16 + (lane >> 4) + 4 * g;
+        const int c = col0 + wc * 32 + j * 16 + (lane & 15);
+        if (r <= n && c < n && c <= r) S[(int64_t)r * n + c] = acc[i][j][g];
+      }
 }
 
 // backward substitution step for panel k0: x_k = invL_kk^T y_k (recomputed by every workgroup), then
@@ -191,21 +328,36 @@ __global__ __launch_bounds__(256) void k_chol_back(const double* __restrict__ S,
   __shared__ double xk[NB];
   __shared__ double part[4][NB];
   const int t = threadIdx.x;
-  if (t < NB) {
+  const int col = t & 63, rq = t >> 6;
+  {
+    // rows r = rq, rq+4, ... of column `col` of the (zero-padded, lower-triangular) inverse
     double s = 0.0;
-    if (t < nb)
-      for (int r = t; r < nb; ++r) s += invL[r * NB + t] * y[k0 + r];
+#pragma unroll
+    for (int i = 0; i < NB / 4; ++i) {
+      const int r = rq + 4 * i;
+      const double yv = r < nb ? y[k0 + r] : 0.0;
+      s += invL[r * NB + col] * yv;
+    }
+    part[rq][col] = s;
+  }
+  __syncthreads();
+  if (t < NB) {
+    const double s = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
     xk[t] = s;
     if (blockIdx.x == 0 && t < nb) x[k0 + t] = s;
   }
   __syncthreads();
   if (k0 == 0) return;
-  const int c = blockIdx.x * NB + (t & 63);
-  const int rq = t >> 6;  // 4 row groups
+  const int c = blockIdx.x * NB + col;
   double s = 0.0;
-  if (c < k0)
-    for (int r = rq; r < nb; r += 4) s += S[(int64_t)(k0 + r) * n + c] * xk[r];
-  part[rq][t & 63] = s;
+  if (c < k0) {
+#pragma unroll
+    for (int i = 0; i < NB / 4; ++i) {
+      const int r = rq + 4 * i;
+      if (r < nb) s += S[(int64_t)(k0 + r) * n + c] * xk[r];
+    }
+  }
+  part[rq][col] = s;
   __syncthreads();
   if (t < NB && c < k0) y[c] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
 }
@@ -229,7 +381,8 @@ int launch_solve_reduced(double* S, int n, double* da, void* ws, int32_t* info, 
   for (int k = 0; k < np; ++k) {
     const int k0 = k * NB;
     const int nb = (n - k0) < NB ? (n - k0) : NB;
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, st, S, n, k0, nb, invL + (int64_t)k * NB * NB, info);
+    static const int dbg = getenv("SFM_BA_DIAG_DBG") ? atoi(getenv("SFM_BA_DIAG_DBG")) : 0;
+    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, st, S, n, k0, nb, invL + (int64_t)k * NB * NB, info, dbg);
     const int rows_below = n + 1 - (k0 + nb);  // includes the right-hand-side row
     const int ntile = (rows_below + NB - 1) / NB;
     if (ntile > 0) {

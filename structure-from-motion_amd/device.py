@@ -77,7 +77,8 @@ class DeviceProblem:
     C_STEP = 0.1   # :94
     X_STEP = 0.5   # :100
 
-    def __init__(self, K, R, T, X, cam_idx, pt_idx, x_true, n_cams=None, group=None, check=True, device=None):
+    def __init__(self, K, R, T, X, cam_idx, pt_idx, x_true, n_cams=None, group=None, check=True, device=None,
+                 sharded=None):
         self.lib = _lib.load()
         self.device = _dev(device)
         self.group = group
@@ -86,6 +87,9 @@ class DeviceProblem:
             import torch.distributed as dist
 
             self.world = dist.get_world_size(group)
+        # sharded flow: damping left out of the local U, system summed over the group, damping
+        # added once afterwards (forced on for a 1-rank group by sharded=True, for testing)
+        self.sharded = (self.world > 1) if sharded is None else bool(sharded)
         R = np.asarray(R, dtype=np.float64).reshape(-1, 3, 3)
         self.m = int(R.shape[0]) if n_cams is None else int(n_cams)
         assert R.shape[0] == self.m
@@ -94,7 +98,7 @@ class DeviceProblem:
         cam_idx = np.ascontiguousarray(cam_idx, dtype=np.int32)
         pt_idx = np.ascontiguousarray(pt_idx, dtype=np.int32)
         self.N = int(cam_idx.shape[0])
-        sharded = self.world > 1
+        sharded = self.sharded
         hinted = sharded or not check
         self.plan = Plan(cam_idx, pt_idx, n_cams_hint=self.m if hinted else 0,
                          n_pts_hint=self.n if hinted else 0, check=check)
@@ -178,7 +182,7 @@ class DeviceProblem:
 
     def assemble(self, mu, weights=None, x_true=None, x_pred=None, A=None, B=None):
         p = _lib.ptr
-        mu_u = mu if self.world == 1 else 0.0
+        mu_u = 0.0 if self.sharded else mu
         n7 = self.n7
         if self.plan.n_blocks < self.m * (self.m + 1) // 2:
             # camera pairs without a shared point are not written by the kernels; the previous
@@ -189,7 +193,7 @@ class DeviceProblem:
             p(self.x_true if x_true is None else x_true), p(self.x_pred if x_pred is None else x_pred),
             p(weights), float(mu), float(mu_u), p(self.S), p(self.e), p(self.U), p(self.eps_a),
             p(self.V_inv), p(self.eps_b), None, p(self.workspace), _stream()))
-        if self.world > 1:
+        if self.sharded:
             import torch.distributed as dist
 
             dist.all_reduce(self.sys[: (n7 + 1) * n7], group=self.group)
@@ -220,7 +224,7 @@ class DeviceProblem:
         _lib.check(self.lib.sfm_ba_cost_partial(self.plan.handle, p(self.P), p(self.X), p(self.cam_idx),
                                                 p(self.pt_idx), p(self.x_true), p(self.ssq), p(self.workspace),
                                                 _stream()))
-        if self.world > 1:
+        if self.sharded:
             import torch.distributed as dist
 
             dist.all_reduce(self.ssq, group=self.group)
