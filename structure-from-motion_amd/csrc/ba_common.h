@@ -12,13 +12,12 @@ namespace sfmba {
 constexpr int kGroupSlots = 256;   // observations handled by one workgroup of the per-point kernels
 constexpr int kCamChunk = 1024;    // observations per per-camera work item
 constexpr int kCamThreads = 128;   // threads of a per-camera work item
-constexpr int kPairChunk = 512;    // (obs, obs) entries per camera-pair work item (one wave each)
+constexpr int kPairChunk = 512;   // (obs, obs) entries per camera-pair work item (one wave each)
+constexpr int kPairPad = 64;        // valid records / T rows kept behind the last entry
 
 struct PairEntry {
   int32_t obs_a;  // observation (caller order) of the block's row camera j
   int32_t obs_b;  // observation of the block's column camera k (same point)
-  int32_t tslot;  // index of the point's 2x2 coupling matrix for this pair
-  int32_t pad;
 };
 
 }  // namespace sfmba
@@ -32,6 +31,7 @@ struct sfm_ba_plan {
   int32_t* d_perm = nullptr;      // [N] slot -> observation position in caller order
   int32_t* d_slot_cam = nullptr;  // [N] camera of the slot
   int32_t* d_tp_ptr = nullptr;    // [n+1] first pair slot of the point (k(k+1)/2 per point)
+  int32_t* d_pair_entry = nullptr;  // [pairs] pair slot -> position of its entry in d_entries (= row of T)
   int32_t* d_grp_pt = nullptr;    // [n_groups+1] first point of each workgroup's range
   int32_t n_groups = 0;
   int64_t n_pair_slots = 0;

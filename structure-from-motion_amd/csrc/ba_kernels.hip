@@ -121,28 +121,18 @@ __global__ void k_camera_prepare(const double* __restrict__ R, const double* __r
 }
 
 // ------------------------------------------------------------------------------------------
-// per-observation Jacobian blocks and prediction: one lane per observation
+// per-observation Jacobian blocks and prediction: one lane per observation.  The observation
+// list is sorted by camera in the reference's order, so almost every wave sees one camera: its
+// record is then read through the scalar cache (one fetch per wave instead of 56 doubles per
+// lane through the vector cache).  A and B rows are parked in the wave's LDS slice and written
+// out as whole 1 KiB wave-rows (lane l stores piece p*64+l), not as 112/48-byte rows per lane.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_jacobian(
-    const double* __restrict__ blk, const double* __restrict__ P, const double* __restrict__ X,
-    const int32_t* __restrict__ cam, const int32_t* __restrict__ pt, int64_t N,
-    double* __restrict__ A, double* __restrict__ B, double* __restrict__ xp) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
-  const int c = cam[i];
-  const int p = pt[i];
-  const double* cb = blk + (int64_t)SFM_BA_CAM_BLK * c;
-  const double x0 = X[3 * (int64_t)p], x1 = X[3 * (int64_t)p + 1], x2 = X[3 * (int64_t)p + 2];
+struct JacOut {
+  double a0[4], a1[4], b0[3], b1[3];
+};
 
-  if (xp) {
-    const double* pm = P + 12 * (int64_t)c;
-    const double h0 = pm[0] * x0 + pm[1] * x1 + pm[2] * x2 + pm[3];
-    const double h1 = pm[4] * x0 + pm[5] * x1 + pm[6] * x2 + pm[7];
-    const double h2 = pm[8] * x0 + pm[9] * x1 + pm[10] * x2 + pm[11];
-    st2(xp + 2 * i, h0 / h2, h1 / h2);
-  }
-  if (!A && !B) return;
-
+template <typename RecPtr>
+__device__ __forceinline__ void jacobian_rows(RecPtr cb, double x0, double x1, double x2, JacOut& o) {
   double mu_[3], mv_[3], mw_[3], d[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -157,40 +147,105 @@ __global__ __launch_bounds__(256) void k_jacobian(
   const double v = mv_[0] * d[0] + mv_[1] * d[1] + mv_[2] * d[2];
   const double w = mw_[0] * d[0] + mw_[1] * d[1] + mw_[2] * d[2];
   const double w2 = w * w;
-  double b0[3], b1[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    b0[k] = (w * mu_[k] - u * mw_[k]) / w2;
-    b1[k] = (w * mv_[k] - v * mw_[k]) / w2;
+    o.b0[k] = (w * mu_[k] - u * mw_[k]) / w2;
+    o.b1[k] = (w * mv_[k] - v * mw_[k]) / w2;
+  }
+  const double fx = cb[52], fy = cb[53], ox = cb[54], oy = cb[55];
+  // gq[r][q] = sum_i d[i] * dRdQ[3r+i][q]
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const double g0 = d[0] * cb[12 + 0 + q] + d[1] * cb[12 + 4 + q] + d[2] * cb[12 + 8 + q];
+    const double g1 = d[0] * cb[12 + 12 + q] + d[1] * cb[12 + 16 + q] + d[2] * cb[12 + 20 + q];
+    const double g2 = d[0] * cb[12 + 24 + q] + d[1] * cb[12 + 28 + q] + d[2] * cb[12 + 32 + q];
+    const double du = fx * g0 + ox * g2;
+    const double dv = fy * g1 + oy * g2;
+    o.a0[q] = (w * du - u * g2) / w2;
+    o.a1[q] = (w * dv - v * g2) / w2;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_jacobian(
+    const double* __restrict__ blk, const double* __restrict__ P, const double* __restrict__ X,
+    const int32_t* __restrict__ cam, const int32_t* __restrict__ pt, int64_t N,
+    double* __restrict__ A, double* __restrict__ B, double* __restrict__ xp) {
+  __shared__ __attribute__((aligned(16))) double sh[4][64 * 20];  // per wave: A rows [64][14], B rows [64][6]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wbase = (int64_t)blockIdx.x * 256 + 64 * wave;  // first observation of this wave
+  if (wbase >= N) return;
+  const int64_t i = wbase + lane;
+  const bool live = i < N;
+  const int64_t ic = live ? i : N - 1;
+  const int c = cam[ic];
+  const int p = pt[ic];
+  const double x0 = X[3 * (int64_t)p], x1 = X[3 * (int64_t)p + 1], x2 = X[3 * (int64_t)p + 2];
+  const int c_first = __builtin_amdgcn_readfirstlane(c);
+  const bool uniform = __all(c == c_first);
+
+  if (xp) {
+    double h0, h1, h2;
+    if (uniform) {
+      const double* pm = P + 12 * (int64_t)c_first;
+      h0 = pm[0] * x0 + pm[1] * x1 + pm[2] * x2 + pm[3];
+      h1 = pm[4] * x0 + pm[5] * x1 + pm[6] * x2 + pm[7];
+      h2 = pm[8] * x0 + pm[9] * x1 + pm[10] * x2 + pm[11];
+    } else {
+      const double* pm = P + 12 * (int64_t)c;
+      h0 = pm[0] * x0 + pm[1] * x1 + pm[2] * x2 + pm[3];
+      h1 = pm[4] * x0 + pm[5] * x1 + pm[6] * x2 + pm[7];
+      h2 = pm[8] * x0 + pm[9] * x1 + pm[10] * x2 + pm[11];
+    }
+    if (live) st2(xp + 2 * i, h0 / h2, h1 / h2);
+  }
+  if (!A && !B) return;
+
+  JacOut o;
+  if (uniform)
+    jacobian_rows(blk + (int64_t)SFM_BA_CAM_BLK * c_first, x0, x1, x2, o);
+  else
+    jacobian_rows(blk + (int64_t)SFM_BA_CAM_BLK * c, x0, x1, x2, o);
+
+  double* sa = sh[wave];
+  double* sb = sa + 64 * 14;
+  {
+    double* ra = sa + 14 * lane;
+    st2(ra, o.a0[0], o.a0[1]);
+    st2(ra + 2, o.a0[2], o.a0[3]);
+    st2(ra + 4, -o.b0[0], -o.b0[1]);
+    st2(ra + 6, -o.b0[2], o.a1[0]);
+    st2(ra + 8, o.a1[1], o.a1[2]);
+    st2(ra + 10, o.a1[3], -o.b1[0]);
+    st2(ra + 12, -o.b1[1], -o.b1[2]);
+    double* rb = sb + 6 * lane;
+    st2(rb, o.b0[0], o.b0[1]);
+    st2(rb + 2, o.b0[2], o.b1[0]);
+    st2(rb + 4, o.b1[1], o.b1[2]);
+  }
+  // same wave wrote and reads: LDS operations of one wave complete in order
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  const int nlive = (N - wbase) < 64 ? (int)(N - wbase) : 64;
+  if (A) {
+    double* ga = A + 14 * wbase;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const int piece = 64 * q + lane;  // 16-byte piece of the wave's [64][14] block
+      if (piece < 7 * nlive) {
+        const double2 v2 = ld2(sa + 2 * piece);
+        st2(ga + 2 * piece, v2.x, v2.y);
+      }
+    }
   }
   if (B) {
-    double* o = B + 6 * i;
-    st2(o, b0[0], b0[1]);
-    st2(o + 2, b0[2], b1[0]);
-    st2(o + 4, b1[1], b1[2]);
-  }
-  if (A) {
-    const double fx = cb[52], fy = cb[53], ox = cb[54], oy = cb[55];
-    // gq[r][q] = sum_i d[i] * dRdQ[3r+i][q]
-    double a0[4], a1[4];
+    double* gb = B + 6 * wbase;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const double g0 = d[0] * cb[12 + 0 + q] + d[1] * cb[12 + 4 + q] + d[2] * cb[12 + 8 + q];
-      const double g1 = d[0] * cb[12 + 12 + q] + d[1] * cb[12 + 16 + q] + d[2] * cb[12 + 20 + q];
-      const double g2 = d[0] * cb[12 + 24 + q] + d[1] * cb[12 + 28 + q] + d[2] * cb[12 + 32 + q];
-      const double du = fx * g0 + ox * g2;
-      const double dv = fy * g1 + oy * g2;
-      a0[q] = (w * du - u * g2) / w2;
-      a1[q] = (w * dv - v * g2) / w2;
+    for (int q = 0; q < 3; ++q) {
+      const int piece = 64 * q + lane;
+      if (piece < 3 * nlive) {
+        const double2 v2 = ld2(sb + 2 * piece);
+        st2(gb + 2 * piece, v2.x, v2.y);
+      }
     }
-    double* o = A + 14 * i;
-    st2(o, a0[0], a0[1]);
-    st2(o + 2, a0[2], a0[3]);
-    st2(o + 4, -b0[0], -b0[1]);
-    st2(o + 6, -b0[2], a1[0]);
-    st2(o + 8, a1[1], a1[2]);
-    st2(o + 10, a1[3], -b1[0]);
-    st2(o + 12, -b1[1], -b1[2]);
   }
 }
 
@@ -203,6 +258,7 @@ __global__ __launch_bounds__(256) void k_jacobian(
 __global__ __launch_bounds__(256) void k_point(
     const int32_t* __restrict__ grp_pt, const int32_t* __restrict__ pt_ptr,
     const int32_t* __restrict__ perm, const int32_t* __restrict__ tp_ptr,
+    const int32_t* __restrict__ pair_entry,
     const double* __restrict__ B, const double* __restrict__ xt, const double* __restrict__ xpred,
     const double* __restrict__ wgt, double mu, double* __restrict__ Vinv,
     double* __restrict__ eps_b, double* __restrict__ g, double* __restrict__ T) {
@@ -306,7 +362,7 @@ __global__ __launch_bounds__(256) void k_point(
     int64_t ts = (int64_t)tp_ptr[p0 + lp] + (int64_t)a * k - (int64_t)a * (a - 1) / 2;
     for (int b = a; b < k; ++b, ++ts) {
       const double* q = sBp + 6 * (first + b);
-      double* o = T + 4 * ts;
+      double* o = T + 4 * (int64_t)pair_entry[ts];  // row of T = position of the pair's entry
       st2(o, h00 * q[0] + h01 * q[1] + h02 * q[2], h00 * q[3] + h01 * q[4] + h02 * q[5]);
       st2(o + 2, h10 * q[0] + h11 * q[1] + h12 * q[2], h10 * q[3] + h11 * q[4] + h12 * q[5]);
     }
@@ -408,80 +464,184 @@ __global__ __launch_bounds__(64) void k_camera_finish(
 }
 
 // ------------------------------------------------------------------------------------------
-// camera-pair blocks: S_jk = delta_jk (U_j) - sum over entries A_a^T T A_b.  One wave per work item
-// (a chunk of one block's entries): lane = 8 * g + c, g = entry sub-index 0..7, c = column 0..6 of
-// the block; every lane keeps the 7 rows of its column.  The 8 partial columns are then combined
-// by a fixed xor-butterfly.
+// camera-pair blocks: S_jk = delta_jk (U_j) - sum over entries A_a^T T A_b.  One wave (= one
+// workgroup) per work item (a chunk of one block's entries); a step is 16 entries.
+//
+// Loading: every operand byte is fetched once per wave, straight into the wave's LDS by
+// global_load_lds (lane = 16-byte piece of an entry's A_a row, A_b row, T, or of the entry
+// records themselves; the pieces land back to back, which is exactly the packed [entry][14] /
+// [entry][4] layout).  The loop is latency bound (entry record -> row address -> row), so it runs
+// as a software pipeline entirely on the transfer counter: in iteration s the rows of step s are
+// consumed while the rows of steps s+1, s+2 and the entry records of steps s+3, s+4 are in
+// flight.  Every iteration issues the same 6 transfers (past the item's end they refetch the last
+// step), so `s_waitcnt vmcnt(6)` at the top of iteration s means "everything issued up to
+// iteration s-2 has landed": the rows of step s and the records of step s+2.  All transfers are
+// issued by all 64 lanes with a wave-uniform LDS base (lanes without a piece refetch another
+// lane's piece into padding).  The LDS footprint (18 KiB) is what bounds the waves per SIMD, and
+// with it the instruction issue rate, so images are kept small rather than deep.
+// Arithmetic: lane = 4 * g + h, g = entry of the step, h = column pair {2h, 2h+1} of the block
+// (h = 3 owns column 6 and a dummy); a lane keeps the 7 rows of its two columns, and the 16
+// partial results are combined at the end by a fixed xor-butterfly.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pair_blocks(
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// 16 bytes per lane from `base` + `off` (32-bit byte offset per lane) to LDS byte address
+// `lds_byte` + 16 * lane (wave-uniform base).  Issued from an asm statement so that the compiler
+// does not know a transfer is in flight: it would otherwise guard every later ds_read with
+// `s_waitcnt vmcnt(0)`, and the pipeline below counts the transfers itself.  M0 carries the LDS
+// base and is restored in the same statement.
+__device__ __forceinline__ void dma16(const void* base, unsigned off, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(off), "s"(base), "s"(lds_byte)
+      : "memory");
+}
+
+// LDS byte address of a pointer into a __shared__ array, as a wave-uniform scalar
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)p);
+}
+
+constexpr int kPairStep = 16;  // entries per step
+// bytes of one step's row image: A_a rows [16][14] and A_b rows [16][14], each padded to 128
+// pieces (2 KiB), then T [16][4] padded to 64 pieces (1 KiB)
+constexpr int kPairImgB = 5120;
+constexpr int kPairRing = 2;   // row images
+constexpr int kPairERing = 3;  // entry-record slots (1 KiB each, 128 B used)
+
+__global__ __launch_bounds__(64) void k_pair_blocks(
     int n_items, const int32_t* __restrict__ pit_blk, const int32_t* __restrict__ pit_beg,
     const int32_t* __restrict__ pit_end, const int32_t* __restrict__ pit_part,
     const int32_t* __restrict__ blk_j, const int32_t* __restrict__ blk_k,
     const PairEntry* __restrict__ ent, const double* __restrict__ A, const double* __restrict__ T,
     const double* __restrict__ cam_part, const int32_t* __restrict__ cam_item_ptr, double mu_u, int m,
     double* __restrict__ S, double* __restrict__ spart) {
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= n_items) return;
-  const int lane = threadIdx.x & 63;
-  const int gsub = lane >> 3, c = lane & 7;
-  const int cc = c < 7 ? c : 6;  // lane 7 of each group shadows column 6 and is never stored
-  const int beg = pit_beg[item], end = pit_end[item];
-  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-  for (int i = beg + gsub; i < end; i += 8) {
-    const PairEntry en = ent[i];
-    const double* aa = A + 14 * (int64_t)en.obs_a;
-    const double* ab = A + 14 * (int64_t)en.obs_b;
-    const double* tt = T + 4 * (int64_t)en.tslot;
-    const double2 t0 = ld2(tt), t1 = ld2(tt + 2);
-    const double b0 = ab[cc], b1 = ab[7 + cc];
-    const double p0 = t0.x * b0 + t0.y * b1;
-    const double p1 = t1.x * b0 + t1.y * b1;
+  // one LDS object for row images and record slots
+  __shared__ __attribute__((aligned(16))) double lds[(kPairRing * kPairImgB + kPairERing * 1024) / 8];
+  double* const rows = lds;
+  int32_t* const erec = reinterpret_cast<int32_t*>(lds + kPairRing * kPairImgB / 8);
+  const unsigned rows_b = lds_addr(rows), erec_b = lds_addr(erec);
+  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Consecutive work items
+  // belong to the same or neighbouring camera pairs and re-read the same A rows, so give every
+  // XCD a contiguous eighth of the item list (bijective remap of the workgroup index).
+  const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+  const int item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int lane = threadIdx.x;
+  const int g = lane >> 2, h = lane & 3;
+  const int beg = __builtin_amdgcn_readfirstlane(pit_beg[item]);
+  const int end = __builtin_amdgcn_readfirstlane(pit_end[item]);
+  const int nsteps = (end - beg + kPairStep - 1) / kPairStep;
+  const int last_base = beg + kPairStep * (nsteps - 1);
+  // row pieces: a 16-entry row block is 112 pieces of 16 bytes; this lane carries piece `lane`
+  // (row r0) and piece 64 + lane (row r1; lanes 48..63 have none and refetch their first piece)
+  const int r0 = lane / 7, c0 = lane - 7 * r0;
+  const bool has1 = lane < 48;
+  const int r1 = has1 ? (64 + lane) / 7 : r0, c1 = has1 ? (64 + lane) - 7 * ((64 + lane) / 7) : c0;
+  // entry records of step q -> slot q % kPairRing (8 pieces; the other lanes refetch them)
+  auto edma = [&](int q) {
+    const int i0 = min(beg + kPairStep * q, last_base);
+    dma16(ent, 8u * (unsigned)(i0 + 2 * (lane & 7)), erec_b + 1024 * (q % kPairERing));
+  };
+  // rows and T of step q -> image q % kPairRing (5 transfers); needs the step's records in LDS
+  auto rdma = [&](int q) {
+    const int32_t* er = erec + 256 * (q % kPairERing);
+    const unsigned base = rows_b + kPairImgB * (q % kPairRing);
+    const int2 ea = *reinterpret_cast<const int2*>(er + 2 * r0);
+    const int2 eb = *reinterpret_cast<const int2*>(er + 2 * r1);
+    dma16(A, 112u * (unsigned)ea.x + 16u * c0, base);
+    dma16(A, 112u * (unsigned)eb.x + 16u * c1, base + 1024);
+    dma16(A, 112u * (unsigned)ea.y + 16u * c0, base + 2048);
+    dma16(A, 112u * (unsigned)eb.y + 16u * c1, base + 2048 + 1024);
+    const int i0 = min(beg + kPairStep * q, last_base);
+    dma16(T, 32u * (unsigned)(i0 + ((lane >> 1) & 15)) + 16u * (lane & 1), base + 4096);
+  };
+  double acc0[7] = {0, 0, 0, 0, 0, 0, 0}, acc1[7] = {0, 0, 0, 0, 0, 0, 0};
+  auto consume = [&](int q) {
+    const int i0 = beg + kPairStep * q;
+    const double* ba = rows + (kPairImgB / 8) * (q % kPairRing);
+    const double* bb = ba + 256;
+    const double* bt = ba + 512 + 4 * g;
+    double2 t0 = ld2(bt), t1 = ld2(bt + 2);
+    if (i0 + g >= end) t0 = t1 = make_double2(0.0, 0.0);  // past the item's last entry
+    const double2 b0 = ld2(bb + 14 * g + 2 * h);  // A_b[0][2h], A_b[0][2h+1]
+    const double b10 = bb[14 * g + 7 + 2 * h], b11 = bb[14 * g + 8 + 2 * h];
+    const double p00 = t0.x * b0.x + t0.y * b10, p10 = t1.x * b0.x + t1.y * b10;
+    const double p01 = t0.x * b0.y + t0.y * b11, p11 = t1.x * b0.y + t1.y * b11;
     double a[14];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) {
-      const double2 v2 = ld2(aa + 2 * q);
-      a[2 * q] = v2.x;
-      a[2 * q + 1] = v2.y;
+    for (int q2 = 0; q2 < 7; ++q2) {
+      const double2 v2 = ld2(ba + 14 * g + 2 * q2);
+      a[2 * q2] = v2.x;
+      a[2 * q2 + 1] = v2.y;
     }
 #pragma unroll
-    for (int r = 0; r < 7; ++r) acc[r] += a[r] * p0 + a[7 + r] * p1;
+    for (int r = 0; r < 7; ++r) {
+      acc0[r] = fma(a[7 + r], p10, fma(a[r], p00, acc0[r]));
+      acc1[r] = fma(a[7 + r], p11, fma(a[r], p01, acc1[r]));
+    }
+  };
+  // 6 transfers per iteration (5 row/T + 1 record); records run two steps ahead of their rows
+  edma(0);
+  edma(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  rdma(0);
+  edma(2);
+  rdma(1);
+  edma(3);
+  for (int s = 0; s < nsteps; ++s) {
+    // all but the 6 youngest transfers have landed: the rows of step s, the records of step s+2
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    consume(s);
+    rdma(s + 2);  // into the image just consumed
+    edma(s + 4);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be landing when the LDS is released
 #pragma unroll
   for (int r = 0; r < 7; ++r) {
-    double v = acc[r];
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    acc[r] = v;
+    double v = acc0[r], w = acc1[r];
+#pragma unroll
+    for (int sft = 4; sft < 64; sft <<= 1) {
+      v += __shfl_xor(v, sft);
+      w += __shfl_xor(w, sft);
+    }
+    acc0[r] = v;
+    acc1[r] = w;
   }
-  if (gsub != 0 || c >= 7) return;
+  if (g != 0) return;
   const int part = pit_part[item];
+  const int ncol = h < 3 ? 2 : 1;
   if (part >= 0) {
     double* o = spart + (int64_t)part * 49;
 #pragma unroll
-    for (int r = 0; r < 7; ++r) o[7 * r + c] = acc[r];
+    for (int r = 0; r < 7; ++r) {
+      o[7 * r + 2 * h] = acc0[r];
+      if (ncol == 2) o[7 * r + 2 * h + 1] = acc1[r];
+    }
     return;
   }
   const int b = pit_blk[item];
   const int j = blk_j[b], k = blk_k[b];
   const int64_t ld = 7 * (int64_t)m;
-  if (j == k) {
-    // U_j from the per-camera item partials (upper triangle, fixed order)
+  for (int cs = 0; cs < ncol; ++cs) {
+    const int c = 2 * h + cs;
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
-      const int lo = r < c ? r : c, hi = r < c ? c : r;
-      const int idx = lo * 7 - lo * (lo - 1) / 2 + (hi - lo);
-      double u = 0.0;
-      for (int it = cam_item_ptr[j]; it < cam_item_ptr[j + 1]; ++it) u += cam_part[(int64_t)it * SFM_BA_CAM_RED + idx];
-      if (r == c) u += mu_u;
-      S[(7 * (int64_t)j + r) * ld + 7 * k + c] = u - acc[r];
-    }
-  } else {
-#pragma unroll
-    for (int r = 0; r < 7; ++r) {
-      const double v = -acc[r];
-      S[(7 * (int64_t)j + r) * ld + 7 * k + c] = v;
-      S[(7 * (int64_t)k + c) * ld + 7 * j + r] = v;
+      const double av = cs == 0 ? acc0[r] : acc1[r];
+      if (j == k) {
+        // U_j from the per-camera item partials (upper triangle, fixed order)
+        const int lo = r < c ? r : c, hi = r < c ? c : r;
+        const int idx = lo * 7 - lo * (lo - 1) / 2 + (hi - lo);
+        double u = 0.0;
+        for (int it = cam_item_ptr[j]; it < cam_item_ptr[j + 1]; ++it) u += cam_part[(int64_t)it * SFM_BA_CAM_RED + idx];
+        if (r == c) u += mu_u;
+        S[(7 * (int64_t)j + r) * ld + 7 * k + c] = u - av;
+      } else {
+        S[(7 * (int64_t)j + r) * ld + 7 * k + c] = -av;
+        S[(7 * (int64_t)k + c) * ld + 7 * j + r] = -av;
+      }
     }
   }
 }
@@ -779,7 +939,7 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
     {
     ProfScope ps(KID_POINT, st);
     hipLaunchKernelGGL(k_point, dim3(p->n_groups), dim3(256), 0, st, p->d_grp_pt, p->d_pt_ptr, p->d_perm,
-                       p->d_tp_ptr, B, xt, xp, w, mu, Vinv, eps_b, g, T);
+                       p->d_tp_ptr, p->d_pair_entry, B, xt, xp, w, mu, Vinv, eps_b, g, T);
   }
     int rc = check_launch("k_point");
     if (rc) return rc;
@@ -803,7 +963,7 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
   if (p->n_pair_items > 0 && S) {
     {
     ProfScope ps(KID_PAIR_BLOCKS, st);
-    hipLaunchKernelGGL(k_pair_blocks, dim3((p->n_pair_items + 3) / 4), dim3(256), 0, st, p->n_pair_items,
+    hipLaunchKernelGGL(k_pair_blocks, dim3(p->n_pair_items), dim3(64), 0, st, p->n_pair_items,
                        p->d_pit_blk, p->d_pit_beg, p->d_pit_end, p->d_pit_part, p->d_blk_j, p->d_blk_k,
                        p->d_entries, A, T, campart, p->d_cam_item_ptr, mu_u, p->m, S, spart);
   }

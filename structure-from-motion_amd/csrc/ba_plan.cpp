@@ -38,7 +38,7 @@ extern "C" const char* sfm_ba_last_hip_error(void) { return sfmba::last_hip_erro
 
 extern "C" void sfm_ba_plan_destroy(sfm_ba_plan* p) {
   if (!p) return;
-  void* ptrs[] = {p->d_pt_ptr,   p->d_perm,     p->d_slot_cam, p->d_tp_ptr,  p->d_grp_pt,  p->d_cam_obs,
+  void* ptrs[] = {p->d_pt_ptr,   p->d_perm,     p->d_slot_cam, p->d_tp_ptr,  p->d_grp_pt,  p->d_cam_obs, p->d_pair_entry,
                   p->d_item_cam, p->d_item_beg, p->d_item_end, p->d_cam_item_ptr, p->d_blk_j, p->d_blk_k,
                   p->d_entries,  p->d_pit_blk,  p->d_pit_beg,  p->d_pit_end, p->d_pit_part, p->d_mb_blk,
                   p->d_mb_part,  p->d_mb_cnt};
@@ -105,6 +105,7 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
         if (slot_cam[s] == slot_cam[s - 1]) return SFM_BA_ENONUNIQUE;
   }
   if (kmax > SFM_BA_MAX_VIEWS || kmax > kGroupSlots) return SFM_BA_ETOOBIG;
+  if (N * 112 >= (int64_t(1) << 32)) return SFM_BA_ETOOBIG;  // 32-bit byte offsets into A
 
   sfm_ba_plan* p = new (std::nothrow) sfm_ba_plan();
   if (!p) return SFM_BA_EINVAL;
@@ -127,7 +128,7 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
       in_group += k;
       tp_ptr[i] = (int32_t)pairs;
       pairs += (int64_t)k * (k + 1) / 2;
-      if (pairs >= (int64_t(1) << 31)) {
+      if ((pairs + kPairPad) * 32 >= (int64_t(1) << 32)) {  // 32-bit byte offsets into T
         delete p;
         return SFM_BA_ETOOBIG;
       }
@@ -154,6 +155,7 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   // ---- camera-pair blocks (j <= k) and their entries, ordered by (j, k) then by point ----
   std::vector<int32_t> blk_j, blk_k, blk_ptr;
   std::vector<PairEntry> entries;
+  std::vector<int32_t> pair_entry((size_t)pairs);
   {
     std::vector<int64_t> cnt((size_t)m * m, 0);
     for (int32_t i = 0; i < n; ++i)
@@ -184,14 +186,16 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
           PairEntry en;
           en.obs_a = perm[sa];
           en.obs_b = perm[sb];
-          en.tslot = tp_ptr[i] + a * k - a * (a - 1) / 2 + (b - a);
-          en.pad = 0;
+          pair_entry[(size_t)tp_ptr[i] + a * k - a * (a - 1) / 2 + (b - a)] = (int32_t)at;
           entries[(size_t)at++] = en;
         }
     }
   }
   p->n_blocks = (int32_t)blk_j.size();
   p->n_entries = (int64_t)entries.size();
+  // the camera-pair kernel fetches whole 32-entry steps: keep one step of valid records (and, in
+  // the workspace, of T rows) behind the last entry
+  entries.resize(entries.size() + kPairPad, PairEntry{0, 0});
 
   std::vector<int32_t> pit_blk, pit_beg, pit_end, pit_part, mb_blk, mb_part, mb_cnt;
   int32_t n_parts = 0;
@@ -224,6 +228,7 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   up(perm, &p->d_perm);
   up(slot_cam, &p->d_slot_cam);
   up(tp_ptr, &p->d_tp_ptr);
+  up(pair_entry, &p->d_pair_entry);
   up(grp_pt, &p->d_grp_pt);
   if (!cam_sorted) up(by_cam, &p->d_cam_obs);
   up(item_cam, &p->d_item_cam);
@@ -251,7 +256,7 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   p->ws_g = off;
   off = align256(off + N * 2 * (int64_t)sizeof(double));
   p->ws_T = off;
-  off = align256(off + pairs * 4 * (int64_t)sizeof(double));
+  off = align256(off + (pairs + kPairPad) * 4 * (int64_t)sizeof(double));
   p->ws_campart = off;
   off = align256(off + (int64_t)std::max(p->n_items, 1) * SFM_BA_CAM_RED * (int64_t)sizeof(double));
   p->ws_spart = off;

@@ -73,8 +73,13 @@ def _views(rng, m: int, n: int, k, visibility: str) -> tuple[np.ndarray, np.ndar
     if kmax > m:
         raise ValueError("views per point exceeds number of cameras")
     if visibility == "banded":
-        # k consecutive cameras from a random start (no wrap-around: S is block-banded)
+        # k consecutive cameras from a random start (no wrap-around: S is block-banded).  Point
+        # ids ascend with the first observing camera, as they do in the incremental pipeline
+        # that feeds the reference's BA: new points are appended to the map when a frame is
+        # registered (/root/reference/src/map.py:17-37, src/pipeline.py:121-122).
         start = rng.integers(0, m - kk + 1)
+        order = np.argsort(start, kind="stable")
+        start, kk = start[order], kk[order]
         offs = np.arange(kmax)[None, :]
         cams = start[:, None] + offs
     elif visibility == "uniform":
