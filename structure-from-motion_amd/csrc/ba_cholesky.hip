@@ -4,17 +4,22 @@
 // part of the panel solves.  Then a blocked backward substitution L^T x = y.
 //
 // Per panel of NB = 64 columns:
-//   k_chol_diag   : one workgroup factors the 64 x 64 diagonal block and inverts its factor.  The
-//                   block is handled as 4 x 4 sub-blocks of 16: a 16 x 16 sub-block is factored and
-//                   inverted by one wave in registers (row per lane, cross-lane reads instead of
-//                   LDS round trips and workgroup barriers); the rest is small LDS products.
+//   k_chol_diag   : one workgroup factors the 64 x 64 diagonal block.  The block is handled as
+//                   4 x 4 sub-blocks of 16: a 16 x 16 sub-block is factored by one wave in
+//                   registers (row per lane, cross-lane reads instead of LDS round trips and
+//                   workgroup barriers), the rows under it are solved one lane per row, the rest
+//                   is updated from LDS.
+//                   Its inverse (needed by the panel kernel) is built from the four 16 x 16
+//                   inverses (one wave each) and small products on the matrix cores.
 //   k_chol_panel  : rows below the block (and the right-hand-side row) times inv(L_kk)^T   [MFMA]
+//                   All-zero 64-row tiles are flagged and skipped here and in the two kernels
+//                   below: S is block sparse whenever far-apart cameras share no point, and the
+//                   factor keeps those zeros outside the profile.
 //   k_chol_update : trailing lower-triangle tiles  A_ij -= P_i P_j^T                        [MFMA]
-// The two product kernels use v_mfma_f64_16x16x4_f64: a 64 x 64 output tile per workgroup, one
-// 32 x 32 quadrant (2 x 2 MFMA tiles) per wave, operands staged in LDS with a row stride of 66
-// doubles (conflict-free for the one-double-per-lane operand reads).
-#include <cstdlib>
-
+//   k_chol_back   : one step of L^T x = y per panel, last panel first.
+// The update kernel uses v_mfma_f64_16x16x4_f64: a 64 x 64 output tile per workgroup, one 32 x 32
+// quadrant (2 x 2 MFMA tiles) per wave, operands staged in LDS with a row stride of 66 doubles
+// (conflict-free for the one-double-per-lane operand reads).
 #include "ba_common.h"
 
 namespace sfmba {
@@ -26,13 +31,14 @@ constexpr int SB = 16;   // sub-block edge inside the diagonal kernel
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 // workspace: [n_panels][NB*NB] inverse diagonal factors, then y[n] (running right-hand side of the
-// backward substitution)
+// backward substitution), then one int per (panel, row tile below it): 1 when that 64 x 64 tile of
+// the factor is entirely zero
 int64_t cholesky_workspace_bytes(int n) {
   const int64_t np = (n + NB - 1) / NB;
-  return (np * NB * NB + (int64_t)np * NB + 64) * (int64_t)sizeof(double);
+  return (np * NB * NB + (int64_t)np * NB + 64) * (int64_t)sizeof(double) + (np * (np + 2) + 64) * (int64_t)sizeof(int32_t);
 }
 
-// value of `v` in lane `lane` (wave-uniform constant lane index)
+// value of `v` in lane `lane` (wave-uniform lane index)
 __device__ __forceinline__ double lane_bcast(double v, int lane) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, lane);
@@ -41,11 +47,11 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
 }
 
 // Factor the 16 x 16 lower-triangular-stored block whose row r sits in lane r (a[0..15], entries
-// above the diagonal ignored) and invert the factor.  On return a[] holds row r of L and x[] row
-// r of L^-1 (zeros above the diagonal).  Returns the index+1 of the first non-positive pivot or 0.
-__device__ __forceinline__ int factor16(double (&a)[SB], double (&x)[SB], int r) {
+// above the diagonal ignored).  On return a[] holds row r of L (zeros above the diagonal) and
+// inv_diag = 1 / L[r][r].  Returns the index+1 of the first non-positive pivot or 0.
+__device__ __forceinline__ int factor16(double (&a)[SB], double& inv_diag, int r) {
   int bad = 0;
-  double inv_diag = 0.0;  // 1 / L[r][r] of this lane's row
+  inv_diag = 0.0;
 #pragma unroll
   for (int j = 0; j < SB; ++j) {
     const double d = lane_bcast(a[j], j);
@@ -63,8 +69,13 @@ __device__ __forceinline__ int factor16(double (&a)[SB], double (&x)[SB], int r)
 #pragma unroll
   for (int c = 0; c < SB; ++c)
     if (c > r) a[c] = 0.0;
-  // inverse by rows: X[q][c] final once rows < q were broadcast; lane r accumulates
-  // acc[c] = sum_{q<r} L[r][q] X[q][c]
+  return bad;
+}
+
+// Inverse of a 16 x 16 lower-triangular factor held one row per lane (a[], zeros above the
+// diagonal; inv_diag = 1 / L[r][r]).  Row q of the inverse is final once rows < q were read across
+// lanes; lane r accumulates acc[c] = sum_{q<r} L[r][q] X[q][c].  x[] receives row r of L^-1.
+__device__ __forceinline__ void inverse16(const double (&a)[SB], double inv_diag, double (&x)[SB], int r) {
   double acc[SB];
 #pragma unroll
   for (int c = 0; c < SB; ++c) {
@@ -73,7 +84,6 @@ __device__ __forceinline__ int factor16(double (&a)[SB], double (&x)[SB], int r)
   }
 #pragma unroll
   for (int q = 0; q < SB; ++q) {
-    // finalise row q in lane q
     if (r == q) {
 #pragma unroll
       for (int c = 0; c < SB; ++c)
@@ -86,14 +96,13 @@ __device__ __forceinline__ int factor16(double (&a)[SB], double (&x)[SB], int r)
       acc[c] += a[q] * xq;  // a[q] = L[r][q], zero for q > r
     }
   }
-  return bad;
 }
 
 __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ S, int n, int k0, int nb,
-                                                   double* __restrict__ invL, int32_t* __restrict__ info, int dbg) {
+                                                   double* __restrict__ invL, int32_t* __restrict__ info) {
   __shared__ double L[NB * LDT];
   __shared__ double X[NB * LDT];
-  __shared__ double M[NB * LDT];
+  __shared__ double invd[NB];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   {
@@ -115,74 +124,88 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ S, int n
   for (int kk = 0; kk < NB / SB; ++kk) {
     const int o = kk * SB;
     __syncthreads();
-    // (1) factor + invert the 16 x 16 diagonal sub-block in registers of wave 0
+    // (1) factor the 16 x 16 diagonal sub-block in registers of wave 0
     if (wave == 0) {
-      double a[SB], x[SB];
+      double a[SB], idg;
       const int r = lane & 15;
 #pragma unroll
       for (int c = 0; c < SB; ++c) a[c] = L[(o + r) * LDT + o + c];
-      int bad = 0;
-      if (!(dbg & 1)) bad = factor16(a, x, r);
-      else {
-#pragma unroll
-        for (int c = 0; c < SB; ++c) x[c] = a[c];
-      }
+      const int bad = factor16(a, idg, r);
       if (lane < SB) {
 #pragma unroll
-        for (int c = 0; c < SB; ++c) {
-          L[(o + r) * LDT + o + c] = a[c];
-          X[(o + r) * LDT + o + c] = x[c];
-        }
+        for (int c = 0; c < SB; ++c) L[(o + r) * LDT + o + c] = a[c];
+        invd[o + r] = idg;
         if (bad && lane == 0 && o + bad <= nb) atomicCAS(info, 0, k0 + o + bad);
       }
     }
     __syncthreads();
     const int below = NB - o - SB;  // rows under the sub-block
-    if (below > 0 && !(dbg & 2)) {
-      // (2) rows below: Bnew = B * Xd^T  (Xd = inverse of the sub-block's factor)
-      for (int idx = t; idx < below * SB; idx += 256) {
-        const int r = o + SB + idx / SB, c = idx % SB;
-        double s = 0.0;
+    if (below > 0) {
+      // (2) rows below: X Ld^T = B by forward substitution, one lane per row
+      if (t < below) {
+        const int r = o + SB + t;
+        double bvals[SB];
 #pragma unroll
-        for (int q = 0; q < SB; ++q) s += L[r * LDT + o + q] * X[(o + c) * LDT + o + q];
-        M[r * LDT + c] = s;
+        for (int c = 0; c < SB; ++c) bvals[c] = L[r * LDT + o + c];
+#pragma unroll
+        for (int c = 0; c < SB; ++c) {
+          double sacc = bvals[c];
+#pragma unroll
+          for (int q = 0; q < c; ++q) sacc -= bvals[q] * L[(o + c) * LDT + o + q];
+          bvals[c] = sacc * invd[o + c];
+        }
+#pragma unroll
+        for (int c = 0; c < SB; ++c) L[r * LDT + o + c] = bvals[c];
       }
       __syncthreads();
-      for (int idx = t; idx < below * SB; idx += 256) {
-        const int r = o + SB + idx / SB, c = idx % SB;
-        L[r * LDT + o + c] = M[r * LDT + c];
-      }
-      // (3) trailing sub-blocks: C -= Bnew Bnew^T (lower part), reading Bnew from M
+      // (3) trailing sub-blocks: C -= X X^T (lower part)
       for (int idx = t; idx < below * below; idx += 256) {
         const int rr = idx / below, cc = idx % below;
         if (cc > rr) continue;
         const int r = o + SB + rr, c = o + SB + cc;
-        double s = 0.0;
+        double sacc = 0.0;
 #pragma unroll
-        for (int q = 0; q < SB; ++q) s += M[r * LDT + q] * M[c * LDT + q];
-        L[r * LDT + c] -= s;
+        for (int q = 0; q < SB; ++q) sacc += L[r * LDT + o + q] * L[c * LDT + o + q];
+        L[r * LDT + c] -= sacc;
       }
     }
   }
   __syncthreads();
-  // 64 x 64 inverse from the 16 x 16 blocks: X_ij = -X_ii sum_{q=j}^{i-1} L_iq X_qj, by distance i-j
-  for (int dist = 1; dist < NB / SB && !(dbg & 4); ++dist) {
-    const int nblk = NB / SB - dist;
-    for (int idx = t; idx < nblk * SB * SB; idx += 256) {
-      const int b = idx / (SB * SB), rr = (idx / SB) % SB, cc = idx % SB;
-      const int bi = b + dist, bj = b;
-      double s = 0.0;
-      for (int q = bj * SB; q < bi * SB; ++q) s += L[(bi * SB + rr) * LDT + q] * X[q * LDT + bj * SB + cc];
-      M[(bi * SB + rr) * LDT + bj * SB + cc] = s;
-    }
-    __syncthreads();
-    for (int idx = t; idx < nblk * SB * SB; idx += 256) {
-      const int b = idx / (SB * SB), rr = (idx / SB) % SB, cc = idx % SB;
-      const int bi = b + dist, bj = b;
-      double s = 0.0;
+  // inverse of the factor.  Diagonal 16 x 16 blocks: wave w inverts block w in registers.
+  {
+    const int o = wave * SB, r = lane & 15;
+    double a[SB], x[SB];
 #pragma unroll
-      for (int q = 0; q < SB; ++q) s += X[(bi * SB + rr) * LDT + bi * SB + q] * M[(bi * SB + q) * LDT + bj * SB + cc];
-      X[(bi * SB + rr) * LDT + bj * SB + cc] = -s;
+    for (int c = 0; c < SB; ++c) a[c] = L[(o + r) * LDT + o + c];
+    inverse16(a, invd[o + r], x, r);
+    if (lane < SB) {
+#pragma unroll
+      for (int c = 0; c < SB; ++c) X[(o + r) * LDT + o + c] = x[c];
+    }
+  }
+  __syncthreads();
+  // Off-diagonal blocks by distance d = i - j:  X_ij = -X_ii (sum_{q=j}^{i-1} L_iq X_qj), one block
+  // per wave on the matrix cores.  The inner sum leaves the accumulator in exactly the lane layout
+  // the second product wants for its B operand (row 4s + (lane >> 4) in register s), so no LDS
+  // round trip sits between the two products.
+  for (int dist = 1; dist < NB / SB; ++dist) {
+    const int bj = wave, bi = wave + dist;
+    if (bi < NB / SB) {
+      const int li = lane & 15, lk = lane >> 4;
+      d4_t m = {0.0, 0.0, 0.0, 0.0};
+      for (int q0 = bj * SB; q0 < bi * SB; q0 += 4) {
+        const double av = L[(bi * SB + li) * LDT + q0 + lk];
+        const double bv = X[(q0 + lk) * LDT + bj * SB + li];
+        m = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, m, 0, 0, 0);
+      }
+      d4_t xo = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int sft = 0; sft < 4; ++sft) {
+        const double av = -X[(bi * SB + li) * LDT + bi * SB + 4 * sft + lk];
+        xo = __builtin_amdgcn_mfma_f64_16x16x4f64(av, m[sft], xo, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) X[(bi * SB + lk + 4 * g) * LDT + bj * SB + li] = xo[g];
     }
     __syncthreads();
   }
@@ -222,19 +245,25 @@ __device__ __forceinline__ void mfma_quadrant(const double* __restrict__ Pa, con
 // P = A_tile * invL^T for the 64-row tiles below the diagonal block; rows up to and including n
 // (the right-hand-side row).  grid.x = number of row tiles.
 __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int n, int k0, int nb,
-                                                    const double* __restrict__ invL) {
+                                                    const double* __restrict__ invL, int32_t* __restrict__ zflag) {
   __shared__ double At[NB * LDT];
   __shared__ double It[NB * LDT];
+  __shared__ int any_nz;
   const int t = threadIdx.x;
   const int row0 = k0 + nb + blockIdx.x * NB;
+  if (t == 0) any_nz = 0;
+  __syncthreads();
   {
     double va[NB * NB / 256], vi[NB * NB / 256];
+    bool nz = false;
 #pragma unroll
     for (int it = 0; it < NB * NB / 256; ++it) {
       const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
       va[it] = (row0 + r <= n && c < nb) ? S[(int64_t)(row0 + r) * n + k0 + c] : 0.0;
       vi[it] = invL[idx];
+      nz |= va[it] != 0.0;
     }
+    if (__any(nz) && (t & 63) == 0) any_nz = 1;
 #pragma unroll
     for (int it = 0; it < NB * NB / 256; ++it) {
       const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
@@ -243,6 +272,10 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int 
     }
   }
   __syncthreads();
+  // an all-zero tile stays zero: record it so that the trailing update and the backward
+  // substitution skip it, and leave
+  if (t == 0) zflag[blockIdx.x] = any_nz ? 0 : 1;
+  if (!any_nz) return;
   const int lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   d4_t acc[2][2];
@@ -265,7 +298,8 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int 
 }
 
 // trailing update A_ij -= P_i P_j^T over lower-triangle tiles (ti >= tj); grid.x enumerates them
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int n, int k0, int nb, int ntile) {
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int n, int k0, int nb, int ntile,
+                                                     const int32_t* __restrict__ zflag) {
   __shared__ double Pi[NB * LDT];
   __shared__ double Pj[NB * LDT];
   const int lin = blockIdx.x;
@@ -274,6 +308,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
   while ((int64_t)ti * (ti + 1) / 2 > lin) --ti;
   const int tj = lin - ti * (ti + 1) / 2;
   if (ti >= ntile) return;
+  if (zflag[ti] | zflag[tj]) return;  // P_i or P_j is all zero
   const int t = threadIdx.x;
   const int base = k0 + nb;
   const int row0 = base + ti * NB, col0 = base + tj * NB;
@@ -324,7 +359,8 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
 // workgroup w removes L[k0.., cols of tile w]^T x_k from y.  Workgroup 0 also stores x_k.
 __global__ __launch_bounds__(256) void k_chol_back(const double* __restrict__ S, int n, int k0, int nb,
                                                    const double* __restrict__ invL, double* __restrict__ y,
-                                                   double* __restrict__ x) {
+                                                   double* __restrict__ x, const int32_t* __restrict__ zflags,
+                                                   int np) {
   __shared__ double xk[NB];
   __shared__ double part[4][NB];
   const int t = threadIdx.x;
@@ -348,6 +384,11 @@ __global__ __launch_bounds__(256) void k_chol_back(const double* __restrict__ S,
   }
   __syncthreads();
   if (k0 == 0) return;
+  // this workgroup's columns are panel j = blockIdx.x; rows k0.. are row tile (k - j - 1) below it
+  {
+    const int k = k0 / NB, j = blockIdx.x;
+    if (zflags[(int64_t)j * (np + 1) + (k - j - 1)]) return;
+  }
   const int c = blockIdx.x * NB + col;
   double s = 0.0;
   if (c < k0) {
@@ -373,6 +414,7 @@ int launch_solve_reduced(double* S, int n, double* da, void* ws, int32_t* info, 
   const int np = (n + NB - 1) / NB;
   double* invL = static_cast<double*>(ws);
   double* y = invL + (int64_t)np * NB * NB;
+  int32_t* zflags = reinterpret_cast<int32_t*>(y + (int64_t)np * NB + 64);  // [np][np+1]
   hipError_t err = hipMemsetAsync(info, 0, sizeof(int32_t), st);
   if (err != hipSuccess) {
     set_hip_error(err, "hipMemsetAsync(info)");
@@ -381,15 +423,16 @@ int launch_solve_reduced(double* S, int n, double* da, void* ws, int32_t* info, 
   for (int k = 0; k < np; ++k) {
     const int k0 = k * NB;
     const int nb = (n - k0) < NB ? (n - k0) : NB;
-    static const int dbg = getenv("SFM_BA_DIAG_DBG") ? atoi(getenv("SFM_BA_DIAG_DBG")) : 0;
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, st, S, n, k0, nb, invL + (int64_t)k * NB * NB, info, dbg);
+    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, st, S, n, k0, nb, invL + (int64_t)k * NB * NB, info);
     const int rows_below = n + 1 - (k0 + nb);  // includes the right-hand-side row
     const int ntile = (rows_below + NB - 1) / NB;
     if (ntile > 0) {
-      hipLaunchKernelGGL(k_chol_panel, dim3(ntile), dim3(256), 0, st, S, n, k0, nb, invL + (int64_t)k * NB * NB);
+      hipLaunchKernelGGL(k_chol_panel, dim3(ntile), dim3(256), 0, st, S, n, k0, nb, invL + (int64_t)k * NB * NB,
+                         zflags + (int64_t)k * (np + 1));
       if (k0 + nb < n) {
         const int64_t nt = (int64_t)ntile * (ntile + 1) / 2;
-        hipLaunchKernelGGL(k_chol_update, dim3((unsigned)nt), dim3(256), 0, st, S, n, k0, nb, ntile);
+        hipLaunchKernelGGL(k_chol_update, dim3((unsigned)nt), dim3(256), 0, st, S, n, k0, nb, ntile,
+                           zflags + (int64_t)k * (np + 1));
       }
     }
   }
@@ -398,7 +441,8 @@ int launch_solve_reduced(double* S, int n, double* da, void* ws, int32_t* info, 
     const int k0 = k * NB;
     const int nb = (n - k0) < NB ? (n - k0) : NB;
     const int nwg = k0 > 0 ? (k0 + NB - 1) / NB : 1;
-    hipLaunchKernelGGL(k_chol_back, dim3(nwg), dim3(256), 0, st, S, n, k0, nb, invL + (int64_t)k * NB * NB, y, da);
+    hipLaunchKernelGGL(k_chol_back, dim3(nwg), dim3(256), 0, st, S, n, k0, nb, invL + (int64_t)k * NB * NB, y, da,
+                       zflags, np);
   }
   err = hipGetLastError();
   if (err != hipSuccess) {
