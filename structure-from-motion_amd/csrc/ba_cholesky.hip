@@ -16,6 +16,7 @@
 //                   below: S is block sparse whenever far-apart cameras share no point, and the
 //                   factor keeps those zeros outside the profile.
 //   k_chol_update : trailing lower-triangle tiles  A_ij -= P_i P_j^T                        [MFMA]
+//                   and, in the workgroup of tile (0, 0), the diagonal work of the next panel
 //   k_chol_back   : one step of L^T x = y per panel, last panel first.
 // The update kernel uses v_mfma_f64_16x16x4_f64: a 64 x 64 output tile per workgroup, one 32 x 32
 // quadrant (2 x 2 MFMA tiles) per wave, operands staged in LDS with a row stride of 66 doubles
@@ -29,6 +30,20 @@ constexpr int LDT = 66;  // LDS row stride in doubles
 constexpr int SB = 16;   // sub-block edge inside the diagonal kernel
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// Diagnostic builds (scripts/probes/diag_stamps.hip) define SFMBA_STAMPS to time the phases of the
+// diagonal factorisation; the library build compiles the stamps away.
+#ifdef SFMBA_STAMPS
+__device__ long long g_stamps[32];
+#define STAMP(i)                                                   \
+  do {                                                             \
+    if (threadIdx.x == 0) g_stamps[i] = (long long)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define STAMP(i) \
+  do {           \
+  } while (0)
+#endif
 
 // workspace: [n_panels][NB*NB] inverse diagonal factors, then y[n] (running right-hand side of the
 // backward substitution), then one int per (panel, row tile below it): 1 when that 64 x 64 tile of
@@ -98,33 +113,22 @@ __device__ __forceinline__ void inverse16(const double (&a)[SB], double inv_diag
   }
 }
 
-__global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ S, int n, int k0, int nb,
-                                                   double* __restrict__ invL, int32_t* __restrict__ info) {
-  __shared__ double L[NB * LDT];
-  __shared__ double X[NB * LDT];
-  __shared__ double invd[NB];
+// Factor the 64 x 64 block held in LDS (L, lower triangle, identity-padded past nb), invert the
+// factor (X), store the factor into S and the inverse into invL.  All 256 threads of the workgroup.
+__device__ __forceinline__ void diag_core(double* __restrict__ L, double* __restrict__ X, double* __restrict__ invd,
+                                          double* __restrict__ S, int n, int k0, int nb, double* __restrict__ invL,
+                                          int32_t* __restrict__ info) {
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
-  {
-    // all 16 loads of a lane are issued before the first LDS store (one memory latency, not 16)
-    double v[NB * NB / 256];
-#pragma unroll
-    for (int it = 0; it < NB * NB / 256; ++it) {
-      const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
-      v[it] = (r == c) ? 1.0 : 0.0;  // identity padding keeps the padded factor well defined
-      if (r < nb && c < nb) v[it] = (c <= r) ? S[(int64_t)(k0 + r) * n + k0 + c] : 0.0;
-    }
-#pragma unroll
-    for (int it = 0; it < NB * NB / 256; ++it) {
-      const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
-      L[r * LDT + c] = v[it];
-      X[r * LDT + c] = 0.0;
-    }
-  }
+  // Sub-block pipeline.  The serial chain is wave 0: factor block kk, solve the next 16 rows
+  // against it, update block (kk+1, kk+1), factor that, ...  Everything else hangs off that chain:
+  // wave 1 inverts block kk, wave 2 solves the remaining rows, waves 2-3 update the rest of the
+  // trailing sub-blocks.  Two workgroup barriers per sub-block order the hand-offs.
+  __syncthreads();
+  STAMP(0);
   for (int kk = 0; kk < NB / SB; ++kk) {
     const int o = kk * SB;
-    __syncthreads();
-    // (1) factor the 16 x 16 diagonal sub-block in registers of wave 0
+    STAMP(1 + 4 * kk);
     if (wave == 0) {
       double a[SB], idg;
       const int r = lane & 15;
@@ -138,52 +142,67 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ S, int n
         if (bad && lane == 0 && o + bad <= nb) atomicCAS(info, 0, k0 + o + bad);
       }
     }
-    __syncthreads();
-    const int below = NB - o - SB;  // rows under the sub-block
-    if (below > 0) {
-      // (2) rows below: X Ld^T = B by forward substitution, one lane per row
-      if (t < below) {
-        const int r = o + SB + t;
-        double bvals[SB];
+    STAMP(2 + 4 * kk);
+    __syncthreads();  // A: block kk is final
+    // rows under the block: X Ld^T = B by forward substitution, one lane per row
+    auto solve_row = [&](int r) {
+      double bvals[SB];
 #pragma unroll
-        for (int c = 0; c < SB; ++c) bvals[c] = L[r * LDT + o + c];
+      for (int c = 0; c < SB; ++c) bvals[c] = L[r * LDT + o + c];
 #pragma unroll
-        for (int c = 0; c < SB; ++c) {
-          double sacc = bvals[c];
+      for (int c = 0; c < SB; ++c) {
+        double sacc = bvals[c];
 #pragma unroll
-          for (int q = 0; q < c; ++q) sacc -= bvals[q] * L[(o + c) * LDT + o + q];
-          bvals[c] = sacc * invd[o + c];
+        for (int q = 0; q < c; ++q) sacc -= bvals[q] * L[(o + c) * LDT + o + q];
+        bvals[c] = sacc * invd[o + c];
+      }
+#pragma unroll
+      for (int c = 0; c < SB; ++c) L[r * LDT + o + c] = bvals[c];
+    };
+    auto update_elem = [&](int r, int c) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int q = 0; q < SB; ++q) sacc += L[r * LDT + o + q] * L[c * LDT + o + q];
+      L[r * LDT + c] -= sacc;
+    };
+    if (wave == 0) {
+      if (kk < NB / SB - 1) {
+        if (lane < SB) solve_row(o + SB + lane);
+        // same wave wrote and reads: LDS operations of one wave complete in order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        for (int idx = lane; idx < SB * SB; idx += 64) {
+          const int rr = idx / SB, cc = idx % SB;
+          if (cc <= rr) update_elem(o + SB + rr, o + SB + cc);
         }
-#pragma unroll
-        for (int c = 0; c < SB; ++c) L[r * LDT + o + c] = bvals[c];
       }
-      __syncthreads();
-      // (3) trailing sub-blocks: C -= X X^T (lower part)
-      for (int idx = t; idx < below * below; idx += 256) {
-        const int rr = idx / below, cc = idx % below;
-        if (cc > rr) continue;
-        const int r = o + SB + rr, c = o + SB + cc;
-        double sacc = 0.0;
+    } else if (wave == 1) {
+      const int r = lane & 15;
+      double a[SB], x[SB];
 #pragma unroll
-        for (int q = 0; q < SB; ++q) sacc += L[r * LDT + o + q] * L[c * LDT + o + q];
-        L[r * LDT + c] -= sacc;
+      for (int c = 0; c < SB; ++c) a[c] = L[(o + r) * LDT + o + c];
+      inverse16(a, invd[o + r], x, r);
+      if (lane < SB) {
+#pragma unroll
+        for (int c = 0; c < SB; ++c) X[(o + r) * LDT + o + c] = x[c];
+      }
+    } else if (wave == 2) {
+      const int r = o + 2 * SB + lane;
+      if (r < NB) solve_row(r);
+    }
+    STAMP(3 + 4 * kk);
+    __syncthreads();  // B: all rows under block kk are solved
+    STAMP(4 + 4 * kk);
+    if (wave >= 2) {
+      // trailing sub-blocks except (kk+1, kk+1): rows from o+32, columns from o+16
+      const int nr = NB - o - 2 * SB, nc = NB - o - SB;
+      for (int idx = t - 128; idx < nr * nc; idx += 128) {
+        const int r = o + 2 * SB + idx / nc, c = o + SB + idx % nc;
+        if (c <= r) update_elem(r, c);
       }
     }
   }
   __syncthreads();
-  // inverse of the factor.  Diagonal 16 x 16 blocks: wave w inverts block w in registers.
-  {
-    const int o = wave * SB, r = lane & 15;
-    double a[SB], x[SB];
-#pragma unroll
-    for (int c = 0; c < SB; ++c) a[c] = L[(o + r) * LDT + o + c];
-    inverse16(a, invd[o + r], x, r);
-    if (lane < SB) {
-#pragma unroll
-      for (int c = 0; c < SB; ++c) X[(o + r) * LDT + o + c] = x[c];
-    }
-  }
-  __syncthreads();
+  STAMP(17);
   // Off-diagonal blocks by distance d = i - j:  X_ij = -X_ii (sum_{q=j}^{i-1} L_iq X_qj), one block
   // per wave on the matrix cores.  The inner sum leaves the accumulator in exactly the lane layout
   // the second product wants for its B operand (row 4s + (lane >> 4) in register s), so no LDS
@@ -209,6 +228,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ S, int n
     }
     __syncthreads();
   }
+  STAMP(18);
 #pragma unroll
   for (int it = 0; it < NB * NB / 256; ++it) {
     const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
@@ -216,6 +236,34 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ S, int n
     invL[idx] = in ? X[r * LDT + c] : 0.0;
     if (in && c <= r) S[(int64_t)(k0 + r) * n + k0 + c] = L[r * LDT + c];
   }
+  STAMP(19);
+}
+
+// first panel only: later diagonal blocks are factored by the workgroup of k_chol_update that
+// produced them
+__global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ S, int n, int k0, int nb,
+                                                   double* __restrict__ invL, int32_t* __restrict__ info) {
+  __shared__ double L[NB * LDT];
+  __shared__ double X[NB * LDT];
+  __shared__ double invd[NB];
+  const int t = threadIdx.x;
+  {
+    // all 16 loads of a lane are issued before the first LDS store (one memory latency, not 16)
+    double v[NB * NB / 256];
+#pragma unroll
+    for (int it = 0; it < NB * NB / 256; ++it) {
+      const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
+      v[it] = (r == c) ? 1.0 : 0.0;  // identity padding keeps the padded factor well defined
+      if (r < nb && c < nb) v[it] = (c <= r) ? S[(int64_t)(k0 + r) * n + k0 + c] : 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < NB * NB / 256; ++it) {
+      const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
+      L[r * LDT + c] = v[it];
+      X[r * LDT + c] = 0.0;
+    }
+  }
+  diag_core(L, X, invd, S, n, k0, nb, invL, info);
 }
 
 // 64 x 64 x 64 product on the matrix cores: acc (2 x 2 MFMA tiles of this wave's 32 x 32 quadrant)
@@ -297,18 +345,25 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int 
       }
 }
 
-// trailing update A_ij -= P_i P_j^T over lower-triangle tiles (ti >= tj); grid.x enumerates them
+// trailing update A_ij -= P_i P_j^T over lower-triangle tiles (ti >= tj); grid.x enumerates them.
+// The workgroup of tile (0, 0) - the next diagonal block - keeps its result on chip and goes
+// straight on to factor it (diag_core), so the next panel needs no separate diagonal launch and
+// that factorisation overlaps the rest of the update.
 __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int n, int k0, int nb, int ntile,
-                                                     const int32_t* __restrict__ zflag) {
+                                                     const int32_t* __restrict__ zflag,
+                                                     double* __restrict__ invL_next, int32_t* __restrict__ info) {
   __shared__ double Pi[NB * LDT];
   __shared__ double Pj[NB * LDT];
+  __shared__ double invd[NB];
   const int lin = blockIdx.x;
   int ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
   while ((int64_t)(ti + 1) * (ti + 2) / 2 <= lin) ++ti;
   while ((int64_t)ti * (ti + 1) / 2 > lin) --ti;
   const int tj = lin - ti * (ti + 1) / 2;
   if (ti >= ntile) return;
-  if (zflag[ti] | zflag[tj]) return;  // P_i or P_j is all zero
+  const bool zero = (zflag[ti] | zflag[tj]) != 0;  // P_i or P_j is all zero: the tile does not change
+  const bool next_diag = lin == 0;
+  if (zero && !next_diag) return;
   const int t = threadIdx.x;
   const int base = k0 + nb;
   const int row0 = base + ti * NB, col0 = base + tj * NB;
@@ -326,7 +381,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
         const int c = col0 + wc * 32 + j * 16 + (lane & 15);
         acc[i][j][g] = (r <= n && c < n && c <= r) ? S[(int64_t)r * n + c] : 0.0;
       }
-  {
+  if (!zero) {
     double vi[NB * NB / 256], vj[NB * NB / 256];
 #pragma unroll
     for (int it = 0; it < NB * NB / 256; ++it) {
@@ -340,19 +395,43 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
       Pi[r * LDT + c] = vi[it];
       Pj[r * LDT + c] = vj[it];
     }
+    __syncthreads();
+    mfma_quadrant(Pi, Pj, wr, wc, lane, true, acc);
   }
+  if (!next_diag) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int r = row0 + wr * 32 + i * 16 + (lane >> 4) + 4 * g;
+          const int c = col0 + wc * 32 + j * 16 + (lane & 15);
+          if (r <= n && c < n && c <= r) S[(int64_t)r * n + c] = acc[i][j][g];
+        }
+    return;
+  }
+  // tile (0, 0) = diagonal block of the next panel: park it in LDS (the operand buffers are free
+  // once every wave is past its MFMAs) and factor it
+  const int k0n = base, nbn = (n - base) < NB ? (n - base) : NB;
   __syncthreads();
-  mfma_quadrant(Pi, Pj, wr, wc, lane, true, acc);
+  for (int idx = t; idx < NB * LDT; idx += 256) Pj[idx] = 0.0;  // becomes X
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int r = row0 + wr * 32 + i * 16 + (lane >> 4) + 4 * g;
-        const int c = col0 + wc * 32 + j * 16 + (lane & 15);
-        if (r <= n && c < n && c <= r) S[(int64_t)r * n + c] = acc[i][j][g];
+        const int r = wr * 32 + i * 16 + (lane >> 4) + 4 * g;
+        const int c = wc * 32 + j * 16 + (lane & 15);
+        double v = (r == c) ? 1.0 : 0.0;  // identity padding past the matrix edge
+        if (r < nbn && c < nbn) v = (c <= r) ? acc[i][j][g] : 0.0;
+        Pi[r * LDT + c] = v;
+        // rows of this tile under a partial last block (the right-hand-side row) are not part of
+        // the diagonal block: they go back to memory as in every other tile
+        if (r >= nbn && base + r <= n && c < nbn) S[(int64_t)(base + r) * n + base + c] = acc[i][j][g];
       }
+  diag_core(Pi, Pj, invd, S, n, k0n, nbn, invL_next, info);
 }
 
 // backward substitution step for panel k0: x_k = invL_kk^T y_k (recomputed by every workgroup), then
@@ -365,6 +444,18 @@ __global__ __launch_bounds__(256) void k_chol_back(const double* __restrict__ S,
   __shared__ double part[4][NB];
   const int t = threadIdx.x;
   const int col = t & 63, rq = t >> 6;
+  // this workgroup's columns are panel j = blockIdx.x; rows k0.. are row tile (k - j - 1) below it
+  bool skip = k0 == 0;
+  if (k0 > 0) skip = zflags[(int64_t)blockIdx.x * (np + 1) + (k0 / NB - blockIdx.x - 1)] != 0;
+  if (skip && blockIdx.x > 0) return;  // workgroup 0 always runs: it stores x_k
+  // the factor's tile is fetched before x_k is known: its addresses do not depend on it
+  const int c = blockIdx.x * NB + col;
+  double lv[NB / 4];
+#pragma unroll
+  for (int i = 0; i < NB / 4; ++i) {
+    const int r = rq + 4 * i;
+    lv[i] = (!skip && c < k0 && r < nb) ? S[(int64_t)(k0 + r) * n + c] : 0.0;
+  }
   {
     // rows r = rq, rq+4, ... of column `col` of the (zero-padded, lower-triangular) inverse
     double s = 0.0;
@@ -383,21 +474,11 @@ __global__ __launch_bounds__(256) void k_chol_back(const double* __restrict__ S,
     if (blockIdx.x == 0 && t < nb) x[k0 + t] = s;
   }
   __syncthreads();
-  if (k0 == 0) return;
-  // this workgroup's columns are panel j = blockIdx.x; rows k0.. are row tile (k - j - 1) below it
-  {
-    const int k = k0 / NB, j = blockIdx.x;
-    if (zflags[(int64_t)j * (np + 1) + (k - j - 1)]) return;
-  }
-  const int c = blockIdx.x * NB + col;
+  if (skip) return;
   double s = 0.0;
-  if (c < k0) {
 #pragma unroll
-    for (int i = 0; i < NB / 4; ++i) {
-      const int r = rq + 4 * i;
-      if (r < nb) s += S[(int64_t)(k0 + r) * n + c] * xk[r];
-    }
-  }
+  for (int i = 0; i < NB / 4; ++i) s += lv[i] * xk[rq + 4 * i];
+  __syncthreads();
   part[rq][col] = s;
   __syncthreads();
   if (t < NB && c < k0) y[c] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
@@ -423,7 +504,8 @@ int launch_solve_reduced(double* S, int n, double* da, void* ws, int32_t* info, 
   for (int k = 0; k < np; ++k) {
     const int k0 = k * NB;
     const int nb = (n - k0) < NB ? (n - k0) : NB;
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, st, S, n, k0, nb, invL + (int64_t)k * NB * NB, info);
+    // the diagonal block of panel k > 0 was factored by the update of panel k-1
+    if (k == 0) hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, st, S, n, k0, nb, invL, info);
     const int rows_below = n + 1 - (k0 + nb);  // includes the right-hand-side row
     const int ntile = (rows_below + NB - 1) / NB;
     if (ntile > 0) {
@@ -432,7 +514,7 @@ int launch_solve_reduced(double* S, int n, double* da, void* ws, int32_t* info, 
       if (k0 + nb < n) {
         const int64_t nt = (int64_t)ntile * (ntile + 1) / 2;
         hipLaunchKernelGGL(k_chol_update, dim3((unsigned)nt), dim3(256), 0, st, S, n, k0, nb, ntile,
-                           zflags + (int64_t)k * (np + 1));
+                           zflags + (int64_t)k * (np + 1), invL + (int64_t)(k + 1) * NB * NB, info);
       }
     }
   }
