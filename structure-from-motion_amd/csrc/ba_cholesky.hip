@@ -62,23 +62,38 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
 }
 
 // Factor the 16 x 16 lower-triangular-stored block whose row r sits in lane r (a[0..15], entries
-// above the diagonal ignored).  On return a[] holds row r of L (zeros above the diagonal) and
-// inv_diag = 1 / L[r][r].  Returns the index+1 of the first non-positive pivot or 0.
-__device__ __forceinline__ int factor16(double (&a)[SB], double& inv_diag, int r) {
+// above the diagonal ignored); lanes >= 16 may hold further rows of the same 16 columns, which
+// come out forward-substituted (row * L^-T).  On return a[] holds row r of L (zeros above the
+// diagonal for r < 16).  Returns the index+1 of the first non-positive pivot or 0.
+//
+// Columns are eliminated in pairs so that the two reciprocal square roots of a pair - the long
+// dependent part of a column step - run side by side: with the leading 2 x 2 block [a00 a10; a10 a11]
+// and det = a00 a11 - a10^2 the second pivot is det / a00, so 1/sqrt(pivot_1) = rsqrt(det) sqrt(a00).
+// det is formed with the product errors compensated (fma residuals), which keeps it as accurate
+// as the pivot of a column-by-column elimination.
+__device__ __forceinline__ int factor16(double (&a)[SB], int r) {
   int bad = 0;
-  inv_diag = 0.0;
 #pragma unroll
-  for (int j = 0; j < SB; ++j) {
-    const double d = lane_bcast(a[j], j);
-    if (!(d > 0.0) && bad == 0) bad = j + 1;
-    const double rs = rsqrt(d);
-    const double l = (r == j) ? d * rs : a[j] * rs;
-    if (r == j) inv_diag = rs;
-    a[j] = l;
+  for (int j = 0; j < SB; j += 2) {
+    const double a00 = lane_bcast(a[j], j), a10 = lane_bcast(a[j], j + 1), a11 = lane_bcast(a[j + 1], j + 1);
+    const double w = a10 * a10;
+    const double e = fma(a10, a10, -w);
+    const double f = fma(a11, a00, -w);
+    const double det = f - e;
+    if (!(a00 > 0.0) && bad == 0) bad = j + 1;
+    if (!(det > 0.0) && bad == 0) bad = j + 2;
+    const double rs0 = rsqrt(a00), rdet = rsqrt(det);
+    const double l00 = a00 * rs0;
+    const double rs1 = rdet * l00;
+    const double l10 = a10 * rs0;
+    const double l0 = a[j] * rs0;
+    const double l1 = fma(-l0, l10, a[j + 1]) * rs1;
+    a[j] = l0;
+    a[j + 1] = l1;
 #pragma unroll
-    for (int c = j + 1; c < SB; ++c) {
-      const double lc = lane_bcast(l, c);
-      a[c] -= l * lc;
+    for (int c = j + 2; c < SB; ++c) {
+      a[c] = fma(-l0, lane_bcast(l0, c), a[c]);
+      a[c] = fma(-l1, lane_bcast(l1, c), a[c]);
     }
   }
 #pragma unroll
@@ -87,154 +102,170 @@ __device__ __forceinline__ int factor16(double (&a)[SB], double& inv_diag, int r
   return bad;
 }
 
-// Inverse of a 16 x 16 lower-triangular factor held one row per lane (a[], zeros above the
-// diagonal; inv_diag = 1 / L[r][r]).  Row q of the inverse is final once rows < q were read across
-// lanes; lane r accumulates acc[c] = sum_{q<r} L[r][q] X[q][c].  x[] receives row r of L^-1.
-__device__ __forceinline__ void inverse16(const double (&a)[SB], double inv_diag, double (&x)[SB], int r) {
-  double acc[SB];
-#pragma unroll
-  for (int c = 0; c < SB; ++c) {
-    acc[c] = 0.0;
-    x[c] = 0.0;
-  }
-#pragma unroll
-  for (int q = 0; q < SB; ++q) {
-    if (r == q) {
-#pragma unroll
-      for (int c = 0; c < SB; ++c)
-        if (c < q) x[c] = -inv_diag * acc[c];
-      x[q] = inv_diag;
-    }
-#pragma unroll
-    for (int c = 0; c <= q; ++c) {
-      const double xq = lane_bcast(x[c], q);
-      acc[c] += a[q] * xq;  // a[q] = L[r][q], zero for q > r
-    }
-  }
-}
-
 // Factor the 64 x 64 block held in LDS (L, lower triangle, identity-padded past nb), invert the
-// factor (X), store the factor into S and the inverse into invL.  All 256 threads of the workgroup.
-__device__ __forceinline__ void diag_core(double* __restrict__ L, double* __restrict__ X, double* __restrict__ invd,
-                                          double* __restrict__ S, int n, int k0, int nb, double* __restrict__ invL,
+// factor (X, any contents on entry), store the factor into S and the lower triangle of the inverse into
+// invL (entries above the diagonal of invL are never written: readers mask them).  256 threads.
+//
+// Phase kk = 16-column block column kk.  Waves 0 and 1 share one copy of the register
+// factorisation: wave 0 holds one row of block column kk per lane (rows 16 kk .. 63) - the lanes
+// below the diagonal block see exactly the same column operations, which is the forward
+// substitution that finishes their rows - and wave 1 holds the diagonal block and the identity,
+// which comes out as the transposed inverse of the diagonal block at no extra latency.  Between
+// two factorisations only the three tiles of the next block column take a rank-16 MFMA update;
+// everything else (the other tiles' updates, block row kk of the inverse
+// X_kj = -X_kk sum_{q=j}^{kk-1} L_kq X_qj, the stores of finished block columns / rows) is done by
+// waves 2 and 3 while waves 0 and 1 factor the next block column.
+__device__ __forceinline__ void diag_core(double* __restrict__ L, double* __restrict__ X, double* __restrict__ S,
+                                          int n, int k0, int nb, double* __restrict__ invL,
                                           int32_t* __restrict__ info) {
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  // Sub-block pipeline.  The serial chain is wave 0: factor block kk, solve the next 16 rows
-  // against it, update block (kk+1, kk+1), factor that, ...  Everything else hangs off that chain:
-  // wave 1 inverts block kk, wave 2 solves the remaining rows, waves 2-3 update the rest of the
-  // trailing sub-blocks.  Two workgroup barriers per sub-block order the hand-offs.
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  constexpr int NS = NB / SB;
+  const int li = lane & 15, lk = lane >> 4;
+
+  // tile (bi, bc) -= L[rows of bi, block column kc] L[rows of bc, block column kc]^T
+  auto upd_tile = [&](int bi, int bc, int kc) {
+    d4_t c4;
+    double av[4], bv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) c4[g] = L[(bi * SB + lk + 4 * g) * LDT + bc * SB + li];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      av[q] = -L[(bi * SB + li) * LDT + kc * SB + 4 * q + lk];
+      bv[q] = L[(bc * SB + li) * LDT + kc * SB + 4 * q + lk];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], c4, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) L[(bi * SB + lk + 4 * g) * LDT + bc * SB + li] = c4[g];
+  };
+  // dst tile = -X_(bi,bi) sum_{q = q_lo}^{q_hi - 1} L[rows of bi, 4q..4q+3] X[4q..4q+3, cols of bj].  The
+  // inner sum leaves the accumulator in exactly the lane layout the second product wants for its
+  // B operand (row 4 s + (lane >> 4) in register s): no LDS round trip between the two products.
+  auto x_job = [&](int bi, int bj, int q_lo, int q_hi, double* dst) {
+    constexpr int QMAX = (NS - 1) * SB / 4;
+    const int cnt = q_hi - q_lo;  // wave-uniform
+    double av[QMAX], bv[QMAX], xv[4];
+#pragma unroll
+    for (int i = 0; i < QMAX; ++i) {
+      const int q = q_lo + i;
+      av[i] = i < cnt ? L[(bi * SB + li) * LDT + 4 * q + lk] : 0.0;
+      bv[i] = i < cnt ? X[(4 * q + lk) * LDT + bj * SB + li] : 0.0;
+    }
+#pragma unroll
+    for (int sft = 0; sft < 4; ++sft) xv[sft] = -X[(bi * SB + li) * LDT + bi * SB + 4 * sft + lk];
+    d4_t m = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < QMAX; ++i)
+      if (i < cnt) m = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[i], m, 0, 0, 0);
+    d4_t xo = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int sft = 0; sft < 4; ++sft) xo = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[sft], m[sft], xo, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dst[(lk + 4 * g) * LDT + li] = xo[g];
+  };
+  // one wave: block column kc of the factor (rows 16 kc .. 63) to S
+  auto store_l_col = [&](int kc) {
+    const int cnt = (NB - kc * SB) * SB;
+    for (int idx = lane; idx < cnt; idx += 64) {
+      const int r = kc * SB + idx / SB, c = kc * SB + idx % SB;
+      if (r < nb && c <= r) S[(int64_t)(k0 + r) * n + k0 + c] = L[r * LDT + c];
+    }
+  };
+  // one wave: block row br of the inverse (columns 0 .. 16 br + 15) to invL
+  auto store_x_row = [&](int br) {
+    const int w = (br + 1) * SB;
+    for (int idx = lane; idx < SB * w; idx += 64) {
+      const int r = br * SB + idx / w, c = idx % w;
+      if (c <= r) invL[r * NB + c] = X[r * LDT + c];
+    }
+  };
+
   __syncthreads();
   STAMP(0);
-  for (int kk = 0; kk < NB / SB; ++kk) {
+  for (int kk = 0; kk < NS; ++kk) {
     const int o = kk * SB;
     STAMP(1 + 4 * kk);
-    if (wave == 0) {
-      double a[SB], idg;
-      const int r = lane & 15;
+    if (wave < 2) {
+      const int row = o + lane;
+      const bool from_l = wave == 0 ? row < NB : lane < SB;
+      double a[SB];
 #pragma unroll
-      for (int c = 0; c < SB; ++c) a[c] = L[(o + r) * LDT + o + c];
-      const int bad = factor16(a, idg, r);
-      if (lane < SB) {
+      for (int c = 0; c < SB; ++c) {
+        a[c] = from_l ? L[row * LDT + o + c] : 0.0;
+        if (wave == 1 && lane - SB == c) a[c] = 1.0;
+      }
+      const int bad = factor16(a, lane);
+      if (wave == 0) {
+        if (row < NB) {
 #pragma unroll
-        for (int c = 0; c < SB; ++c) L[(o + r) * LDT + o + c] = a[c];
-        invd[o + r] = idg;
+          for (int c = 0; c < SB; ++c) L[row * LDT + o + c] = a[c];
+        }
         if (bad && lane == 0 && o + bad <= nb) atomicCAS(info, 0, k0 + o + bad);
+      } else if (lane >= SB && lane < 2 * SB) {
+        // lane 16 + q holds row q of inv(L_kk)^T
+#pragma unroll
+        for (int c = 0; c < SB; ++c) X[(o + c) * LDT + o + lane - SB] = a[c];
+      }
+    } else if (kk > 0) {
+      // in the shadow of the factorisation: what the previous block column left to do
+      const int pk = kk - 1;
+      if (wave == 2) {
+        if (pk == 0) {
+          upd_tile(2, 2, 0);
+          upd_tile(3, 3, 0);
+        } else if (pk == 1) {
+          upd_tile(3, 3, 1);
+          x_job(1, 0, 0, 4, X + (1 * SB) * LDT);
+        } else {
+          x_job(2, 0, 0, 8, X + (2 * SB) * LDT);
+        }
+      } else {
+        if (pk == 0) upd_tile(3, 2, 0);
+        if (pk == 2) x_job(2, 1, 4, 8, X + (2 * SB) * LDT + SB);
+        store_l_col(pk);
+        if (pk >= 1) store_x_row(pk - 1);
       }
     }
     STAMP(2 + 4 * kk);
-    __syncthreads();  // A: block kk is final
-    // rows under the block: X Ld^T = B by forward substitution, one lane per row
-    auto solve_row = [&](int r) {
-      double bvals[SB];
-#pragma unroll
-      for (int c = 0; c < SB; ++c) bvals[c] = L[r * LDT + o + c];
-#pragma unroll
-      for (int c = 0; c < SB; ++c) {
-        double sacc = bvals[c];
-#pragma unroll
-        for (int q = 0; q < c; ++q) sacc -= bvals[q] * L[(o + c) * LDT + o + q];
-        bvals[c] = sacc * invd[o + c];
-      }
-#pragma unroll
-      for (int c = 0; c < SB; ++c) L[r * LDT + o + c] = bvals[c];
-    };
-    auto update_elem = [&](int r, int c) {
-      double sacc = 0.0;
-#pragma unroll
-      for (int q = 0; q < SB; ++q) sacc += L[r * LDT + o + q] * L[c * LDT + o + q];
-      L[r * LDT + c] -= sacc;
-    };
-    if (wave == 0) {
-      if (kk < NB / SB - 1) {
-        if (lane < SB) solve_row(o + SB + lane);
-        // same wave wrote and reads: LDS operations of one wave complete in order
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        for (int idx = lane; idx < SB * SB; idx += 64) {
-          const int rr = idx / SB, cc = idx % SB;
-          if (cc <= rr) update_elem(o + SB + rr, o + SB + cc);
-        }
-      }
-    } else if (wave == 1) {
-      const int r = lane & 15;
-      double a[SB], x[SB];
-#pragma unroll
-      for (int c = 0; c < SB; ++c) a[c] = L[(o + r) * LDT + o + c];
-      inverse16(a, invd[o + r], x, r);
-      if (lane < SB) {
-#pragma unroll
-        for (int c = 0; c < SB; ++c) X[(o + r) * LDT + o + c] = x[c];
-      }
-    } else if (wave == 2) {
-      const int r = o + 2 * SB + lane;
-      if (r < NB) solve_row(r);
-    }
+    __syncthreads();  // block column kk of L and X_kk are final
     STAMP(3 + 4 * kk);
-    __syncthreads();  // B: all rows under block kk are solved
+    if (kk < NS - 1 && wave < NS - 1 - kk) upd_tile(kk + 1 + wave, kk + 1, kk);
     STAMP(4 + 4 * kk);
-    if (wave >= 2) {
-      // trailing sub-blocks except (kk+1, kk+1): rows from o+32, columns from o+16
-      const int nr = NB - o - 2 * SB, nc = NB - o - SB;
-      for (int idx = t - 128; idx < nr * nc; idx += 128) {
-        const int r = o + 2 * SB + idx / nc, c = o + SB + idx % nc;
-        if (c <= r) update_elem(r, c);
-      }
-    }
+    if (kk < NS - 1) __syncthreads();
   }
-  __syncthreads();
+  // block row 3 of the inverse; the long sum of X_30 is split over two waves, the second half parked
+  // in the (structurally zero, never stored) block (0, 3) of X
+  if (wave == 0) {
+    x_job(3, 0, 0, 6, X + (3 * SB) * LDT);
+  } else if (wave == 1) {
+    x_job(3, 1, 4, 12, X + (3 * SB) * LDT + SB);
+  } else if (wave == 2) {
+    x_job(3, 2, 8, 12, X + (3 * SB) * LDT + 2 * SB);
+  } else {
+    x_job(3, 0, 6, 12, X + 3 * SB);
+  }
   STAMP(17);
-  // Off-diagonal blocks by distance d = i - j:  X_ij = -X_ii (sum_{q=j}^{i-1} L_iq X_qj), one block
-  // per wave on the matrix cores.  The inner sum leaves the accumulator in exactly the lane layout
-  // the second product wants for its B operand (row 4s + (lane >> 4) in register s), so no LDS
-  // round trip sits between the two products.
-  for (int dist = 1; dist < NB / SB; ++dist) {
-    const int bj = wave, bi = wave + dist;
-    if (bi < NB / SB) {
-      const int li = lane & 15, lk = lane >> 4;
-      d4_t m = {0.0, 0.0, 0.0, 0.0};
-      for (int q0 = bj * SB; q0 < bi * SB; q0 += 4) {
-        const double av = L[(bi * SB + li) * LDT + q0 + lk];
-        const double bv = X[(q0 + lk) * LDT + bj * SB + li];
-        m = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, m, 0, 0, 0);
-      }
-      d4_t xo = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int sft = 0; sft < 4; ++sft) {
-        const double av = -X[(bi * SB + li) * LDT + bi * SB + 4 * sft + lk];
-        xo = __builtin_amdgcn_mfma_f64_16x16x4f64(av, m[sft], xo, 0, 0, 0);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) X[(bi * SB + lk + 4 * g) * LDT + bj * SB + li] = xo[g];
-    }
-    __syncthreads();
-  }
+  __syncthreads();
   STAMP(18);
+  {
+    // what is left to store: block rows 2 and 3 of the inverse, the last diagonal block of the factor
+    double xv[8], lv;
 #pragma unroll
-  for (int it = 0; it < NB * NB / 256; ++it) {
-    const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
-    const bool in = r < nb && c < nb;
-    invL[idx] = in ? X[r * LDT + c] : 0.0;
-    if (in && c <= r) S[(int64_t)(k0 + r) * n + k0 + c] = L[r * LDT + c];
+    for (int it = 0; it < 8; ++it) {
+      const int idx = t + 256 * it, r = 2 * SB + idx / NB, c = idx % NB;
+      xv[it] = c <= r ? X[r * LDT + c] : 0.0;
+      if (r >= 3 * SB && c < SB) xv[it] += X[(r - 3 * SB) * LDT + 3 * SB + c];
+    }
+    const int lr = 3 * SB + t / SB, lc = 3 * SB + t % SB;
+    lv = L[lr * LDT + lc];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = t + 256 * it, r = 2 * SB + idx / NB, c = idx % NB;
+      if (c <= r) invL[r * NB + c] = xv[it];
+    }
+    if (lr < nb && lc <= lr) S[(int64_t)(k0 + lr) * n + k0 + lc] = lv;
   }
   STAMP(19);
 }
@@ -245,7 +276,6 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ S, int n
                                                    double* __restrict__ invL, int32_t* __restrict__ info) {
   __shared__ double L[NB * LDT];
   __shared__ double X[NB * LDT];
-  __shared__ double invd[NB];
   const int t = threadIdx.x;
   {
     // all 16 loads of a lane are issued before the first LDS store (one memory latency, not 16)
@@ -260,10 +290,9 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ S, int n
     for (int it = 0; it < NB * NB / 256; ++it) {
       const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
       L[r * LDT + c] = v[it];
-      X[r * LDT + c] = 0.0;
     }
   }
-  diag_core(L, X, invd, S, n, k0, nb, invL, info);
+  diag_core(L, X, S, n, k0, nb, invL, info);
 }
 
 // 64 x 64 x 64 product on the matrix cores: acc (2 x 2 MFMA tiles of this wave's 32 x 32 quadrant)
@@ -308,7 +337,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int 
     for (int it = 0; it < NB * NB / 256; ++it) {
       const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
       va[it] = (row0 + r <= n && c < nb) ? S[(int64_t)(row0 + r) * n + k0 + c] : 0.0;
-      vi[it] = invL[idx];
+      vi[it] = (c <= r) ? invL[idx] : 0.0;  // only the lower triangle of the inverse is stored
       nz |= va[it] != 0.0;
     }
     if (__any(nz) && (t & 63) == 0) any_nz = 1;
@@ -354,7 +383,6 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
                                                      double* __restrict__ invL_next, int32_t* __restrict__ info) {
   __shared__ double Pi[NB * LDT];
   __shared__ double Pj[NB * LDT];
-  __shared__ double invd[NB];
   const int lin = blockIdx.x;
   int ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
   while ((int64_t)(ti + 1) * (ti + 2) / 2 <= lin) ++ti;
@@ -415,7 +443,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
   // once every wave is past its MFMAs) and factor it
   const int k0n = base, nbn = (n - base) < NB ? (n - base) : NB;
   __syncthreads();
-  for (int idx = t; idx < NB * LDT; idx += 256) Pj[idx] = 0.0;  // becomes X
+  // (Pj becomes the inverse's buffer; every entry that is read is written first)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -431,7 +459,7 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int
         // the diagonal block: they go back to memory as in every other tile
         if (r >= nbn && base + r <= n && c < nbn) S[(int64_t)(base + r) * n + base + c] = acc[i][j][g];
       }
-  diag_core(Pi, Pj, invd, S, n, k0n, nbn, invL_next, info);
+  diag_core(Pi, Pj, S, n, k0n, nbn, invL_next, info);
 }
 
 // backward substitution step for panel k0: x_k = invL_kk^T y_k (recomputed by every workgroup), then
@@ -462,8 +490,11 @@ __global__ __launch_bounds__(256) void k_chol_back(const double* __restrict__ S,
 #pragma unroll
     for (int i = 0; i < NB / 4; ++i) {
       const int r = rq + 4 * i;
-      const double yv = r < nb ? y[k0 + r] : 0.0;
-      s += invL[r * NB + col] * yv;
+      // only the lower triangle of the inverse is stored (rows past nb hold identity padding)
+      const bool on = r < nb && col <= r;
+      const double iv = on ? invL[r * NB + col] : 0.0;
+      const double yv = on ? y[k0 + r] : 0.0;
+      s += iv * yv;
     }
     part[rq][col] = s;
   }
