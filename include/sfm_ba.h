@@ -78,6 +78,11 @@ void sfm_ba_plan_destroy(sfm_ba_plan* plan);
  * point, [4]=number of (obs,obs) pair entries, [5]=number of per-point pair slots (doubles/4 of d_T),
  * [6]=number of per-camera work items, [7]=bytes of device memory held by the plan */
 int sfm_ba_plan_sizes(const sfm_ba_plan* plan, int64_t what[8]);
+/* Half bandwidth of the reduced camera matrix this plan's observations produce: S[r][c] = 0
+ * wherever |r - c| exceeds it (7 (k - j) + 6 for the furthest-apart cameras j <= k that share a
+ * point).  `Indices.shared_point_indices` (src/sparse_ba.py:107-128) is where the reference finds
+ * the same empty blocks, one pair at a time.  A sharded run takes the maximum over its ranks. */
+int32_t sfm_ba_plan_half_bandwidth(const sfm_ba_plan* plan);
 /* bytes of the scratch workspace the assemble / back-substitution entry points need */
 int64_t sfm_ba_plan_workspace_bytes(const sfm_ba_plan* plan);
 
@@ -162,6 +167,13 @@ int sfm_ba_add_diagonal(double* d_S, int32_t n7, double mu, void* stream);
 int64_t sfm_ba_cholesky_workspace_bytes(int32_t n7);
 int sfm_ba_solve_reduced(double* d_S, int32_t n7, double* d_delta_a, void* d_chol_ws,
                          int32_t* d_info, void* stream);
+/* The same solve (src/sparse_ba.py:274-276) for a caller that knows S[r][c] = 0 wherever
+ * |r - c| > half_bandwidth (sfm_ba_plan_half_bandwidth).  With half_bandwidth <= 64 the factorisation
+ * is a chain of 64 x 64 blocks that one workgroup walks in a single launch, substitutions included,
+ * and d_S is only read; wider bands take the general path of sfm_ba_solve_reduced (d_S destroyed).
+ * Entries outside the stated band are never read on the narrow path. */
+int sfm_ba_solve_reduced_banded(double* d_S, int32_t n7, int32_t half_bandwidth, double* d_delta_a,
+                                void* d_chol_ws, int32_t* d_info, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Back-substitution.  Work of `calc_delta_b` (src/sparse_ba.py:279-290):

@@ -36,6 +36,8 @@ SYMBOLS = {
     "sfm_ba_add_diagonal": (_int, [_vp, _i32, _f64, _vp]),
     "sfm_ba_cholesky_workspace_bytes": (_i64, [_i32]),
     "sfm_ba_solve_reduced": (_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
+    "sfm_ba_solve_reduced_banded": (_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "sfm_ba_plan_half_bandwidth": (_i32, [_vp]),
     "sfm_ba_back_substitute": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp]),
     "sfm_ba_update_cameras": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _i32, _i32, _f64, _f64, _vp, _vp]),
     "sfm_ba_cost_partial": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -63,7 +63,14 @@ int64_t sfm_ba_cholesky_workspace_bytes(int32_t n7) { return n7 > 0 ? cholesky_w
 int sfm_ba_solve_reduced(double* d_S, int32_t n7, double* d_delta_a, void* d_chol_ws, int32_t* d_info,
                          void* stream) {
   if (!d_S || !d_delta_a || !d_chol_ws || !d_info || n7 <= 0) return SFM_BA_EINVAL;
-  return launch_solve_reduced(d_S, n7, d_delta_a, d_chol_ws, d_info, static_cast<hipStream_t>(stream));
+  return launch_solve_reduced(d_S, n7, -1, d_delta_a, d_chol_ws, d_info, static_cast<hipStream_t>(stream));
+}
+
+int sfm_ba_solve_reduced_banded(double* d_S, int32_t n7, int32_t half_bandwidth, double* d_delta_a,
+                                void* d_chol_ws, int32_t* d_info, void* stream) {
+  if (!d_S || !d_delta_a || !d_chol_ws || !d_info || n7 <= 0 || half_bandwidth < 0) return SFM_BA_EINVAL;
+  return launch_solve_reduced(d_S, n7, half_bandwidth, d_delta_a, d_chol_ws, d_info,
+                              static_cast<hipStream_t>(stream));
 }
 
 int sfm_ba_back_substitute(const sfm_ba_plan* plan, const double* d_A, const double* d_B, const double* d_weights,

@@ -45,12 +45,15 @@ __device__ long long g_stamps[32];
   } while (0)
 #endif
 
-// workspace: [n_panels][NB*NB] inverse diagonal factors, then y[n] (running right-hand side of the
-// backward substitution), then one int per (panel, row tile below it): 1 when that 64 x 64 tile of
-// the factor is entirely zero
+// workspace: [n_panels][NB*NB] inverse diagonal factors, then y[n_panels * NB + 64] (running
+// right-hand side of the substitutions), then either one int per (panel, row tile below it) - 1 when
+// that 64 x 64 tile of the factor is entirely zero (general path) - or [n_panels][NB*NB]
+// sub-diagonal factor tiles (band path)
 int64_t cholesky_workspace_bytes(int n) {
   const int64_t np = (n + NB - 1) / NB;
-  return (np * NB * NB + (int64_t)np * NB + 64) * (int64_t)sizeof(double) + (np * (np + 2) + 64) * (int64_t)sizeof(int32_t);
+  const int64_t flags = (np * (np + 2) + 64) * (int64_t)sizeof(int32_t);
+  const int64_t tiles = np * NB * NB * (int64_t)sizeof(double);
+  return (np * NB * NB + np * NB + 64) * (int64_t)sizeof(double) + (flags > tiles ? flags : tiles);
 }
 
 // value of `v` in lane `lane` (wave-uniform lane index)
@@ -103,7 +106,7 @@ __device__ __forceinline__ int factor16(double (&a)[SB], int r) {
 }
 
 // Factor the 64 x 64 block held in LDS (L, lower triangle, identity-padded past nb), invert the
-// factor (X, any contents on entry), store the factor into S and the lower triangle of the inverse into
+// factor (X, any contents on entry), store the factor into S (unless S is null) and the lower triangle of the inverse into
 // invL (entries above the diagonal of invL are never written: readers mask them).  256 threads.
 //
 // Phase kk = 16-column block column kk.  Waves 0 and 1 share one copy of the register
@@ -170,7 +173,7 @@ __device__ __forceinline__ void diag_core(double* __restrict__ L, double* __rest
     const int cnt = (NB - kc * SB) * SB;
     for (int idx = lane; idx < cnt; idx += 64) {
       const int r = kc * SB + idx / SB, c = kc * SB + idx % SB;
-      if (r < nb && c <= r) S[(int64_t)(k0 + r) * n + k0 + c] = L[r * LDT + c];
+      if (S != nullptr && r < nb && c <= r) S[(int64_t)(k0 + r) * n + k0 + c] = L[r * LDT + c];
     }
   };
   // one wave: block row br of the inverse (columns 0 .. 16 br + 15) to invL
@@ -248,6 +251,14 @@ __device__ __forceinline__ void diag_core(double* __restrict__ L, double* __rest
   }
   STAMP(17);
   __syncthreads();
+  // fold the parked half of X_30 in and clear its parking place: X is then the complete inverse
+  // (lower blocks; blocks above the diagonal are never touched by this function)
+  {
+    const int r = t / SB, c = t % SB;
+    X[(3 * SB + r) * LDT + c] += X[r * LDT + 3 * SB + c];
+    X[r * LDT + 3 * SB + c] = 0.0;
+  }
+  __syncthreads();
   STAMP(18);
   {
     // what is left to store: block rows 2 and 3 of the inverse, the last diagonal block of the factor
@@ -255,8 +266,7 @@ __device__ __forceinline__ void diag_core(double* __restrict__ L, double* __rest
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int idx = t + 256 * it, r = 2 * SB + idx / NB, c = idx % NB;
-      xv[it] = c <= r ? X[r * LDT + c] : 0.0;
-      if (r >= 3 * SB && c < SB) xv[it] += X[(r - 3 * SB) * LDT + 3 * SB + c];
+      xv[it] = X[r * LDT + c];
     }
     const int lr = 3 * SB + t / SB, lc = 3 * SB + t % SB;
     lv = L[lr * LDT + lc];
@@ -265,7 +275,7 @@ __device__ __forceinline__ void diag_core(double* __restrict__ L, double* __rest
       const int idx = t + 256 * it, r = 2 * SB + idx / NB, c = idx % NB;
       if (c <= r) invL[r * NB + c] = xv[it];
     }
-    if (lr < nb && lc <= lr) S[(int64_t)(k0 + lr) * n + k0 + lc] = lv;
+    if (S != nullptr && lr < nb && lc <= lr) S[(int64_t)(k0 + lr) * n + k0 + lc] = lv;
   }
   STAMP(19);
 }
@@ -515,12 +525,219 @@ __global__ __launch_bounds__(256) void k_chol_back(const double* __restrict__ S,
   if (t < NB && c < k0) y[c] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
 }
 
+// ---- band path -------------------------------------------------------------------------------
+// When S has no non-zero further than 64 places from its diagonal (cameras share points only with
+// near neighbours in index), each panel has one non-zero 64 x 64 tile below its diagonal block and
+// the factorisation is a chain with no parallel slack at all: panel k+1 cannot start before panel k
+// is done.  One workgroup then walks the whole chain without leaving the chip: the diagonal block
+// lives in LDS from its update to its factorisation, the sub-diagonal tile and the next diagonal
+// block are fetched while the current one is being factored, and both substitutions run in the
+// same launch.  S is only read.
+//   invL_ws [np][64*64] inverse diagonal factors (lower triangle), p_ws [np][64*64] sub-diagonal
+//   factor tiles, y_ws [np*64] forward-substituted right-hand side.
+__global__ __launch_bounds__(256) void k_chol_band(const double* __restrict__ S, int n, double* __restrict__ invL_ws,
+                                                   double* __restrict__ p_ws, double* __restrict__ y_ws,
+                                                   double* __restrict__ x_out, int32_t* __restrict__ info) {
+  __shared__ double D[NB * LDT];   // diagonal block -> its factor
+  __shared__ double X[NB * LDT];   // inverse of the factor
+  __shared__ double Bt[NB * LDT];  // sub-diagonal tile of S -> of the factor
+  __shared__ double tv[NB];        // right-hand side of the current panel minus what earlier panels took
+  __shared__ double yv[NB];
+  __shared__ double part[4][NB];
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int np = (n + NB - 1) / NB;
+  const double* rhs = S + (int64_t)n * n;
+  for (int idx = t; idx < NB * LDT; idx += 256) X[idx] = 0.0;
+  {
+    const int nb = n < NB ? n : NB;
+    double v[NB * NB / 256];
+#pragma unroll
+    for (int it = 0; it < NB * NB / 256; ++it) {
+      const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
+      v[it] = (r == c) ? 1.0 : 0.0;  // identity padding keeps the padded factor well defined
+      if (r < nb && c < nb) v[it] = (c <= r) ? S[(int64_t)r * n + c] : 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < NB * NB / 256; ++it) {
+      const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
+      D[r * LDT + c] = v[it];
+    }
+    if (t < NB) tv[t] = t < nb ? rhs[t] : 0.0;
+  }
+  for (int k = 0; k < np; ++k) {
+    const int k0 = k * NB;
+    const int nb = (n - k0) < NB ? (n - k0) : NB;
+    const bool has_next = k + 1 < np;
+    const int k1 = k0 + NB;
+    const int nb1 = has_next ? ((n - k1) < NB ? (n - k1) : NB) : 0;
+    // issued now, used after the factorisation: the tile below the diagonal block, the next
+    // diagonal block (in accumulator layout) and the next piece of the right-hand side
+    double vb[NB * NB / 256];
+    d4_t acc[2][2];
+    double e_next = 0.0;
+    if (has_next) {
+#pragma unroll
+      for (int it = 0; it < NB * NB / 256; ++it) {
+        const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
+        vb[it] = r < nb1 ? S[(int64_t)(k1 + r) * n + k0 + c] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int r = wr * 32 + i * 16 + (lane >> 4) + 4 * g;
+            const int c = wc * 32 + j * 16 + (lane & 15);
+            acc[i][j][g] = (r < nb1 && c <= r) ? S[(int64_t)(k1 + r) * n + k1 + c] : 0.0;
+          }
+      if (t < nb1) e_next = rhs[k1 + t];
+    }
+    diag_core(D, X, nullptr, n, k0, nb, invL_ws + (int64_t)k * NB * NB, info);
+    // forward substitution of this panel: y_k = inv(L_kk) tv
+    {
+      const int r = t & 63, q = t >> 6;
+      double sacc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) sacc += X[r * LDT + 16 * q + c] * tv[16 * q + c];
+      part[q][r] = sacc;
+    }
+    if (has_next) {
+#pragma unroll
+      for (int it = 0; it < NB * NB / 256; ++it) {
+        const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
+        Bt[r * LDT + c] = vb[it];
+      }
+    }
+    __syncthreads();
+    if (t < NB) {
+      const double yk = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+      yv[t] = yk;
+      y_ws[k0 + t] = yk;
+    }
+    if (!has_next) break;
+    // P = B inv(L_kk)^T
+    d4_t pacc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) pacc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+    mfma_quadrant(Bt, X, wr, wc, lane, false, pacc);
+    __syncthreads();  // every wave is done reading Bt (and yv is visible)
+    double* pk = p_ws + (int64_t)k * NB * NB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int r = wr * 32 + i * 16 + (lane >> 4) + 4 * g;
+          const int c = wc * 32 + j * 16 + (lane & 15);
+          Bt[r * LDT + c] = pacc[i][j][g];
+          pk[r * NB + c] = pacc[i][j][g];
+        }
+    __syncthreads();
+    // next diagonal block -= P P^T (the quadrant above the diagonal is not needed); next tv = e - P y
+    if (wave != 1) mfma_quadrant(Bt, Bt, wr, wc, lane, true, acc);
+    {
+      const int r = t & 63, q = t >> 6;
+      double sacc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) sacc += Bt[r * LDT + 16 * q + c] * yv[16 * q + c];
+      part[q][r] = sacc;
+    }
+    if (wave != 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int r = wr * 32 + i * 16 + (lane >> 4) + 4 * g;
+            const int c = wc * 32 + j * 16 + (lane & 15);
+            double v = (r == c) ? 1.0 : 0.0;
+            if (r < nb1 && c < nb1) v = (c <= r) ? acc[i][j][g] : 0.0;
+            D[r * LDT + c] = v;
+          }
+    } else {
+      // the quadrant above the diagonal of the padded block: zeros
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int r = i * 16 + (lane >> 4) + 4 * g;
+            const int c = 32 + j * 16 + (lane & 15);
+            D[r * LDT + c] = 0.0;
+          }
+    }
+    __syncthreads();
+    if (t < NB) tv[t] = e_next - ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t]));
+    // (diag_core opens with a workgroup barrier: D and tv are visible to every wave after it)
+  }
+  __syncthreads();
+  // backward substitution, last panel first: x_k = inv(L_kk)^T (y_k - P_k^T x_{k+1}); yv holds y of the
+  // last panel already.  Thread (col = t & 63, rq = t >> 6) sums rows rq, rq+4, ... of its column.
+  const int col = t & 63, rq = t >> 6;
+  double xi[NB / 4], pv[NB / 4];
+  {
+    const double* il = invL_ws + (int64_t)(np - 1) * NB * NB;
+#pragma unroll
+    for (int i = 0; i < NB / 4; ++i) {
+      const int r = rq + 4 * i;
+      xi[i] = col <= r ? il[r * NB + col] : 0.0;
+      pv[i] = 0.0;
+    }
+  }
+  for (int k = np - 1; k >= 0; --k) {
+    const int k0 = k * NB;
+    const int nb = (n - k0) < NB ? (n - k0) : NB;
+    // z = y_k - P_k^T x_{k+1}   (tv holds x_{k+1}; pv is zero for the last panel)
+    double sacc = 0.0;
+#pragma unroll
+    for (int i = 0; i < NB / 4; ++i) sacc += pv[i] * tv[rq + 4 * i];
+    part[rq][col] = sacc;
+    __syncthreads();
+    if (t < NB) yv[t] = yv[t] - ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t]));
+    __syncthreads();
+    sacc = 0.0;
+#pragma unroll
+    for (int i = 0; i < NB / 4; ++i) sacc += xi[i] * yv[rq + 4 * i];
+    // tiles of the next step are fetched before this step's last reduction
+    double yn = 0.0;
+    if (k > 0) {
+      const double* il = invL_ws + (int64_t)(k - 1) * NB * NB;
+      const double* pl = p_ws + (int64_t)(k - 1) * NB * NB;
+#pragma unroll
+      for (int i = 0; i < NB / 4; ++i) {
+        const int r = rq + 4 * i;
+        xi[i] = col <= r ? il[r * NB + col] : 0.0;
+        pv[i] = pl[r * NB + col];
+      }
+      if (t < NB) yn = y_ws[k0 - NB + t];
+    }
+    __syncthreads();  // every thread has read part[] of the first product
+    part[rq][col] = sacc;
+    __syncthreads();
+    if (t < NB) {
+      const double xk = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+      tv[t] = xk;
+      if (t < nb) x_out[k0 + t] = xk;
+      yv[t] = yn;
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void k_copy_row(const double* __restrict__ src, double* __restrict__ dst, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i];
 }
 
-int launch_solve_reduced(double* S, int n, double* da, void* ws, int32_t* info, hipStream_t st) {
+int launch_solve_reduced(double* S, int n, int half_bandwidth, double* da, void* ws, int32_t* info, hipStream_t st) {
   if (n <= 0) return SFM_BA_OK;
   ProfScope ps(KID_SOLVE, st);
   const int np = (n + NB - 1) / NB;
@@ -531,6 +748,16 @@ int launch_solve_reduced(double* S, int n, double* da, void* ws, int32_t* info, 
   if (err != hipSuccess) {
     set_hip_error(err, "hipMemsetAsync(info)");
     return SFM_BA_EHIP;
+  }
+  if (half_bandwidth >= 0 && half_bandwidth <= NB) {
+    double* p_ws = reinterpret_cast<double*>(zflags);
+    hipLaunchKernelGGL(k_chol_band, dim3(1), dim3(256), 0, st, S, n, invL, p_ws, y, da, info);
+    err = hipGetLastError();
+    if (err != hipSuccess) {
+      set_hip_error(err, "k_chol_band launch");
+      return SFM_BA_EHIP;
+    }
+    return SFM_BA_OK;
   }
   for (int k = 0; k < np; ++k) {
     const int k0 = k * NB;

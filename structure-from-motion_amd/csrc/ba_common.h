@@ -44,6 +44,7 @@ struct sfm_ba_plan {
   int32_t n_items = 0;
   // camera-pair blocks (j <= k) with at least one shared point
   int32_t n_blocks = 0;
+  int32_t max_cam_dist = 0;  // largest k - j over camera pairs (j <= k) that share a point
   int32_t* d_blk_j = nullptr;
   int32_t* d_blk_k = nullptr;
   int64_t n_entries = 0;
@@ -119,6 +120,7 @@ int launch_cost_partial(const sfm_ba_plan* p, const double* P, const double* X, 
                         const int32_t* pt, const double* xt, double* ssq, void* ws, hipStream_t st);
 int launch_cost_finish(const double* ssq, int m, double* cost, hipStream_t st);
 int64_t cholesky_workspace_bytes(int n7);
-int launch_solve_reduced(double* S, int n7, double* da, void* ws, int32_t* info, hipStream_t st);
+// half_bandwidth < 0: dense; otherwise S[r][c] = 0 wherever |r - c| > half_bandwidth
+int launch_solve_reduced(double* S, int n7, int half_bandwidth, double* da, void* ws, int32_t* info, hipStream_t st);
 
 }  // namespace sfmba

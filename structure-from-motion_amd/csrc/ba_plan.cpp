@@ -156,6 +156,7 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   std::vector<int32_t> blk_j, blk_k, blk_ptr;
   std::vector<PairEntry> entries;
   std::vector<int32_t> pair_entry((size_t)pairs);
+  int32_t max_cam_dist = 0;
   {
     std::vector<int64_t> cnt((size_t)m * m, 0);
     for (int32_t i = 0; i < n; ++i)
@@ -171,6 +172,7 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
         }
         blk_j.push_back(j);
         blk_k.push_back(k);
+        max_cam_dist = std::max(max_cam_dist, k - j);
         blk_ptr.push_back((int32_t)total);
         cnt[(size_t)j * m + k] = total;
         total += c;
@@ -192,6 +194,7 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
     }
   }
   p->n_blocks = (int32_t)blk_j.size();
+  p->max_cam_dist = max_cam_dist;
   p->n_entries = (int64_t)entries.size();
   // the camera-pair kernel fetches whole 32-entry steps: keep one step of valid records (and, in
   // the workspace, of T rows) behind the last entry
@@ -277,6 +280,12 @@ extern "C" int sfm_ba_plan_sizes(const sfm_ba_plan* p, int64_t what[8]) {
   what[6] = p->n_items;
   what[7] = p->device_bytes;
   return SFM_BA_OK;
+}
+
+extern "C" int32_t sfm_ba_plan_half_bandwidth(const sfm_ba_plan* p) {
+  // two cameras j <= k share a point only if k - j <= max_cam_dist: the furthest non-zero of S from
+  // its diagonal couples the first parameter of camera j with the last of camera j + max_cam_dist
+  return p ? 7 * p->max_cam_dist + 6 : -1;
 }
 
 extern "C" int64_t sfm_ba_plan_workspace_bytes(const sfm_ba_plan* p) { return p ? p->ws_total : 0; }

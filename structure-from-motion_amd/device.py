@@ -54,6 +54,7 @@ class Plan:
         (self.m, self.n, self.n_obs, self.n_blocks, self.n_entries, self.n_pair_slots,
          self.n_items, self.device_bytes) = [int(v) for v in sizes]
         self.workspace_bytes = int(lib.sfm_ba_plan_workspace_bytes(handle))
+        self.half_bandwidth = int(lib.sfm_ba_plan_half_bandwidth(handle))
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -105,6 +106,15 @@ class DeviceProblem:
         if self.plan.m != self.m or self.plan.n != self.n:
             # the reference's Indices asserts that every id up to the maximum occurs
             raise AssertionError("index lists do not cover every camera / point")
+        # band of the reduced camera matrix: the widest over all shards
+        self.half_bandwidth = self.plan.half_bandwidth
+        if self.sharded and self.world > 1:
+            import torch.distributed as dist
+
+            hb = torch.tensor([self.half_bandwidth], dtype=torch.int64,
+                              device=self.device if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(hb, op=dist.ReduceOp.MAX, group=group)
+            self.half_bandwidth = int(hb.item())
         d = self.device
         K = np.asarray(K, dtype=np.float64)
         if K.ndim == 2:
@@ -184,9 +194,10 @@ class DeviceProblem:
         p = _lib.ptr
         mu_u = 0.0 if self.sharded else mu
         n7 = self.n7
-        if self.plan.n_blocks < self.m * (self.m + 1) // 2:
+        if self.plan.n_blocks < self.m * (self.m + 1) // 2 and (self.sharded or self.half_bandwidth > 64):
             # camera pairs without a shared point are not written by the kernels; the previous
-            # factorisation left fill-in there
+            # factorisation left fill-in there (the narrow-band solve only reads S), and the
+            # all-reduce of a sharded run left the other ranks' blocks there
             self.sys[: n7 * n7].zero_()
         _lib.check(self.lib.sfm_ba_schur_assemble(
             self.plan.handle, p(self.A if A is None else A), p(self.B if B is None else B),
@@ -202,8 +213,8 @@ class DeviceProblem:
 
     def solve(self):
         p = _lib.ptr
-        _lib.check(self.lib.sfm_ba_solve_reduced(p(self.S), self.n7, p(self.delta_a), p(self.chol_ws),
-                                                 p(self.info), _stream()))
+        _lib.check(self.lib.sfm_ba_solve_reduced_banded(p(self.S), self.n7, self.half_bandwidth, p(self.delta_a),
+                                                        p(self.chol_ws), p(self.info), _stream()))
 
     def back_substitute(self, weights=None, update_points=False, A=None, B=None):
         p = _lib.ptr
