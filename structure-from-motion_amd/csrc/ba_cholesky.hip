@@ -34,14 +34,32 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // Diagnostic builds (scripts/probes/diag_stamps.hip) define SFMBA_STAMPS to time the phases of the
 // diagonal factorisation; the library build compiles the stamps away.
 #ifdef SFMBA_STAMPS
-__device__ long long g_stamps[32];
+__device__ long long g_stamps[48];
+__device__ int g_stamp_on = 1;
 #define STAMP(i)                                                   \
   do {                                                             \
-    if (threadIdx.x == 0) g_stamps[i] = (long long)__builtin_amdgcn_s_memtime(); \
+    if (threadIdx.x == 0 && g_stamp_on) g_stamps[i] = (long long)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define STAMP_GATE(on) \
+  do {                 \
+    if (threadIdx.x == 0) g_stamp_on = (on); \
+  } while (0)
+// stamp ordered after `dep` is produced and before its later uses
+#define STAMP_DEP(i, dep)                                                                              \
+  do {                                                                                                 \
+    long long t_;                                                                                      \
+    asm volatile("s_nop 0\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(dep)::"memory"); \
+    if (threadIdx.x == 0) g_stamps[i] = t_;                                                            \
   } while (0)
 #else
 #define STAMP(i) \
   do {           \
+  } while (0)
+#define STAMP_DEP(i, dep) \
+  do {                    \
+  } while (0)
+#define STAMP_GATE(on) \
+  do {                 \
   } while (0)
 #endif
 
@@ -53,7 +71,9 @@ int64_t cholesky_workspace_bytes(int n) {
   const int64_t np = (n + NB - 1) / NB;
   const int64_t flags = (np * (np + 2) + 64) * (int64_t)sizeof(int32_t);
   const int64_t tiles = np * NB * NB * (int64_t)sizeof(double);
-  return (np * NB * NB + np * NB + 64) * (int64_t)sizeof(double) + (flags > tiles ? flags : tiles);
+  const int64_t general = (np * NB * NB + np * NB + 64) * (int64_t)sizeof(double) + (flags > tiles ? flags : tiles);
+  const int64_t reduction = (4 * np * NB * NB + np * NB + 64) * (int64_t)sizeof(double);  // D, B, P_u, P_d, e per block
+  return general > reduction ? general : reduction;
 }
 
 // value of `v` in lane `lane` (wave-uniform lane index)
@@ -118,9 +138,17 @@ __device__ __forceinline__ int factor16(double (&a)[SB], int r) {
 // everything else (the other tiles' updates, block row kk of the inverse
 // X_kj = -X_kk sum_{q=j}^{kk-1} L_kq X_qj, the stores of finished block columns / rows) is done by
 // waves 2 and 3 while waves 0 and 1 factor the next block column.
+struct NoShadow {
+  __device__ __forceinline__ void operator()(int, int) const {}
+};
+
+// `shadow(kk, tt)` is run by waves 2 and 3 (tt = 0..127) at the start of phase kk, while waves 0 and
+// 1 factor block column kk: these two waves have slack in every phase (none of their own work in
+// phase 0), so callers hang independent work there.
+template <class Shadow = NoShadow>
 __device__ __forceinline__ void diag_core(double* __restrict__ L, double* __restrict__ X, double* __restrict__ S,
                                           int n, int k0, int nb, double* __restrict__ invL,
-                                          int32_t* __restrict__ info) {
+                                          int32_t* __restrict__ info, Shadow shadow = Shadow()) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -199,19 +227,25 @@ __device__ __forceinline__ void diag_core(double* __restrict__ L, double* __rest
         a[c] = from_l ? L[row * LDT + o + c] : 0.0;
         if (wave == 1 && lane - SB == c) a[c] = 1.0;
       }
+      if (kk == 1) STAMP_DEP(40, a[15]);
       const int bad = factor16(a, lane);
+      if (kk == 1) STAMP_DEP(41, a[15]);
       if (wave == 0) {
         if (row < NB) {
 #pragma unroll
           for (int c = 0; c < SB; ++c) L[row * LDT + o + c] = a[c];
         }
+        if (kk == 1) STAMP(42);
         if (bad && lane == 0 && o + bad <= nb) atomicCAS(info, 0, k0 + o + bad);
       } else if (lane >= SB && lane < 2 * SB) {
         // lane 16 + q holds row q of inv(L_kk)^T
 #pragma unroll
         for (int c = 0; c < SB; ++c) X[(o + c) * LDT + o + lane - SB] = a[c];
       }
-    } else if (kk > 0) {
+    } else {
+      shadow(kk, t - 128);
+    }
+    if (wave >= 2 && kk > 0) {
       // in the shadow of the factorisation: what the previous block column left to do
       const int pk = kk - 1;
       if (wave == 2) {
@@ -531,22 +565,58 @@ __global__ __launch_bounds__(256) void k_chol_back(const double* __restrict__ S,
 // the factorisation is a chain with no parallel slack at all: panel k+1 cannot start before panel k
 // is done.  One workgroup then walks the whole chain without leaving the chip: the diagonal block
 // lives in LDS from its update to its factorisation, the sub-diagonal tile and the next diagonal
-// block are fetched while the current one is being factored, and both substitutions run in the
-// same launch.  S is only read.
+// block are fetched by the two waves that idle at the start of each diagonal factorisation, and
+// both substitutions run in the same launch.  S is only read.
+//
+// The two 64^3 products per panel (P = B inv(L)^T and D' -= P P^T) are done per 16 x 16 block on the
+// matrix cores, skipping blocks that are structurally zero: inv(L) is lower triangular, and of the
+// sub-diagonal tile B only the blocks near its upper right corner are non-zero when the band is
+// narrower than 64 (a bit mask of the non-zero blocks of B is taken while it is loaded).
 //   invL_ws [np][64*64] inverse diagonal factors (lower triangle), p_ws [np][64*64] sub-diagonal
 //   factor tiles, y_ws [np*64] forward-substituted right-hand side.
+
+// c += (negate ? -1 : 1) * A[block row I, block col kb] B[block row J, block col kb]^T summed over the
+// block columns kb < kb_end whose bit is set in both ma and mb
+__device__ __forceinline__ void block_prod(const double* __restrict__ A, int I, unsigned ma,
+                                           const double* __restrict__ B, int J, unsigned mb, int kb_end,
+                                           bool negate, int li, int lk, d4_t& c) {
+  constexpr int NS = NB / SB;
+  double av[NS][4], bv[NS][4];
+  const unsigned on = ma & mb & ((1u << kb_end) - 1u);
+#pragma unroll
+  for (int kb = 0; kb < NS; ++kb)
+    if ((on >> kb) & 1u) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double a = A[(I * SB + li) * LDT + kb * SB + 4 * q + lk];
+        av[kb][q] = negate ? -a : a;
+        bv[kb][q] = B[(J * SB + li) * LDT + kb * SB + 4 * q + lk];
+      }
+    }
+#pragma unroll
+  for (int kb = 0; kb < NS; ++kb)
+    if ((on >> kb) & 1u) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kb][q], bv[kb][q], c, 0, 0, 0);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_chol_band(const double* __restrict__ S, int n, double* __restrict__ invL_ws,
                                                    double* __restrict__ p_ws, double* __restrict__ y_ws,
                                                    double* __restrict__ x_out, int32_t* __restrict__ info) {
-  __shared__ double D[NB * LDT];   // diagonal block -> its factor
-  __shared__ double X[NB * LDT];   // inverse of the factor
-  __shared__ double Bt[NB * LDT];  // sub-diagonal tile of S -> of the factor
-  __shared__ double tv[NB];        // right-hand side of the current panel minus what earlier panels took
+  constexpr int NS = NB / SB;
+  __shared__ double Dbuf[2][NB * LDT];  // diagonal block -> its factor; the other one receives the next block
+  __shared__ double X[NB * LDT];        // inverse of the factor
+  __shared__ double Bt[NB * LDT];       // sub-diagonal tile of S -> of the factor
+  __shared__ double tv[NB];             // right-hand side of the current panel minus what earlier panels took
   __shared__ double yv[NB];
+  __shared__ double en[NB];
   __shared__ double part[4][NB];
+  __shared__ unsigned bmask_sh;         // bit 4 I + K: block (I, K) of the sub-diagonal tile has a non-zero
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 15, lk = lane >> 4;
   const int np = (n + NB - 1) / NB;
   const double* rhs = S + (int64_t)n * n;
   for (int idx = t; idx < NB * LDT; idx += 256) X[idx] = 0.0;
@@ -562,40 +632,65 @@ __global__ __launch_bounds__(256) void k_chol_band(const double* __restrict__ S,
 #pragma unroll
     for (int it = 0; it < NB * NB / 256; ++it) {
       const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
-      D[r * LDT + c] = v[it];
+      Dbuf[0][r * LDT + c] = v[it];
     }
     if (t < NB) tv[t] = t < nb ? rhs[t] : 0.0;
+    if (t == 0) bmask_sh = 0u;
   }
   for (int k = 0; k < np; ++k) {
+    double* D = Dbuf[k & 1];
+    double* Dn = Dbuf[(k + 1) & 1];
     const int k0 = k * NB;
     const int nb = (n - k0) < NB ? (n - k0) : NB;
     const bool has_next = k + 1 < np;
     const int k1 = k0 + NB;
     const int nb1 = has_next ? ((n - k1) < NB ? (n - k1) : NB) : 0;
-    // issued now, used after the factorisation: the tile below the diagonal block, the next
-    // diagonal block (in accumulator layout) and the next piece of the right-hand side
-    double vb[NB * NB / 256];
-    d4_t acc[2][2];
-    double e_next = 0.0;
-    if (has_next) {
+    STAMP_GATE(k == 1);
+    STAMP(20);
+    // waves 2 and 3, while waves 0 and 1 factor the first block column: the tile below the diagonal
+    // block (with the mask of its non-zero 16 x 16 blocks), the next diagonal block, the next piece
+    // of the right-hand side
+    auto fetch_next = [&](int kk, int tt) {
+      if (!has_next || kk > 1) return;
+      double v[NB * NB / 128];
+      if (kk == 0) {
 #pragma unroll
-      for (int it = 0; it < NB * NB / 256; ++it) {
-        const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
-        vb[it] = r < nb1 ? S[(int64_t)(k1 + r) * n + k0 + c] : 0.0;
+        for (int it = 0; it < NB * NB / 128; ++it) {
+          const int idx = tt + 128 * it, r = idx / NB, c = idx % NB;
+          v[it] = r < nb1 ? S[(int64_t)(k1 + r) * n + k0 + c] : 0.0;
+        }
+        unsigned m = 0u;
+#pragma unroll
+        for (int it = 0; it < NB * NB / 128; ++it) {
+          const int idx = tt + 128 * it, r = idx / NB, c = idx % NB;
+          Bt[r * LDT + c] = v[it];
+          // a wave holds one row here: 16 lanes per block column
+          const unsigned long long nz = __ballot(v[it] != 0.0);
+          const int I = r / SB;
+#pragma unroll
+          for (int kb = 0; kb < NS; ++kb)
+            if ((nz >> (16 * kb)) & 0xffffull) m |= 1u << (4 * I + kb);
+        }
+        if (lane == 0 && m) atomicOr(&bmask_sh, m);
+      } else {
+#pragma unroll
+        for (int it = 0; it < NB * NB / 128; ++it) {
+          const int idx = tt + 128 * it, r = idx / NB, c = idx % NB;
+          v[it] = (r == c) ? 1.0 : 0.0;
+          if (r < nb1 && c < nb1) v[it] = (c <= r) ? S[(int64_t)(k1 + r) * n + k1 + c] : 0.0;
+        }
+        const double ev = (tt < nb1) ? rhs[k1 + tt] : 0.0;
+#pragma unroll
+        for (int it = 0; it < NB * NB / 128; ++it) {
+          const int idx = tt + 128 * it, r = idx / NB, c = idx % NB;
+          Dn[r * LDT + c] = v[it];
+        }
+        if (tt < NB) en[tt] = ev;
       }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int r = wr * 32 + i * 16 + (lane >> 4) + 4 * g;
-            const int c = wc * 32 + j * 16 + (lane & 15);
-            acc[i][j][g] = (r < nb1 && c <= r) ? S[(int64_t)(k1 + r) * n + k1 + c] : 0.0;
-          }
-      if (t < nb1) e_next = rhs[k1 + t];
-    }
-    diag_core(D, X, nullptr, n, k0, nb, invL_ws + (int64_t)k * NB * NB, info);
+    };
+    STAMP(21);
+    diag_core(D, X, nullptr, n, k0, nb, invL_ws + (int64_t)k * NB * NB, info, fetch_next);
+    STAMP(22);
     // forward substitution of this panel: y_k = inv(L_kk) tv
     {
       const int r = t & 63, q = t >> 6;
@@ -604,13 +699,6 @@ __global__ __launch_bounds__(256) void k_chol_band(const double* __restrict__ S,
       for (int c = 0; c < 16; ++c) sacc += X[r * LDT + 16 * q + c] * tv[16 * q + c];
       part[q][r] = sacc;
     }
-    if (has_next) {
-#pragma unroll
-      for (int it = 0; it < NB * NB / 256; ++it) {
-        const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
-        Bt[r * LDT + c] = vb[it];
-      }
-    }
     __syncthreads();
     if (t < NB) {
       const double yk = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
@@ -618,29 +706,56 @@ __global__ __launch_bounds__(256) void k_chol_band(const double* __restrict__ S,
       y_ws[k0 + t] = yk;
     }
     if (!has_next) break;
-    // P = B inv(L_kk)^T
-    d4_t pacc[2][2];
+    STAMP(23);
+    // P = B inv(L_kk)^T.  Wave w owns the four blocks (I, (w - I) mod 4); block (I, J) sums over block
+    // columns kb <= J (inv(L) is lower triangular) in which B has a non-zero block.
+    const unsigned bmask = bmask_sh;
+    // structural mask of P: block (I, J) is non-zero if B has a non-zero block (I, kb) with kb <= J
+    unsigned pmask = 0u;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int I = 0; I < NS; ++I)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) pacc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
-    mfma_quadrant(Bt, X, wr, wc, lane, false, pacc);
+      for (int J = 0; J < NS; ++J)
+        if ((bmask >> (4 * I)) & ((2u << J) - 1u)) pmask |= 1u << (4 * I + J);
+    d4_t pacc[NS];
+#pragma unroll
+    for (int I = 0; I < NS; ++I) {
+      const int J = (wave - I) & 3;
+      pacc[I] = d4_t{0.0, 0.0, 0.0, 0.0};
+      block_prod(Bt, I, (bmask >> (4 * I)) & 15u, X, J, 15u, J + 1, false, li, lk, pacc[I]);
+    }
+    STAMP(24);
     __syncthreads();  // every wave is done reading Bt (and yv is visible)
     double* pk = p_ws + (int64_t)k * NB * NB;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int I = 0; I < NS; ++I) {
+      const int J = (wave - I) & 3;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int r = wr * 32 + i * 16 + (lane >> 4) + 4 * g;
-          const int c = wc * 32 + j * 16 + (lane & 15);
-          Bt[r * LDT + c] = pacc[i][j][g];
-          pk[r * NB + c] = pacc[i][j][g];
-        }
+      for (int g = 0; g < 4; ++g) {
+        const int r = I * SB + lk + 4 * g, c = J * SB + li;
+        Bt[r * LDT + c] = pacc[I][g];
+        pk[r * NB + c] = pacc[I][g];
+      }
+    }
+    if (t == 0) bmask_sh = 0u;  // for the next panel's fetch (a barrier away from its first use)
     __syncthreads();
-    // next diagonal block -= P P^T (the quadrant above the diagonal is not needed); next tv = e - P y
-    if (wave != 1) mfma_quadrant(Bt, Bt, wr, wc, lane, true, acc);
+    STAMP(25);
+    // next diagonal block -= P P^T, lower blocks only: wave w owns the blocks (I, J), J <= I, with
+    // (I + J) mod 4 = w; next tv = e - P y
+#pragma unroll
+    for (int I = 0; I < NS; ++I)
+#pragma unroll
+      for (int J = 0; J <= I; ++J)
+        if (((I + J) & 3) == wave) {
+          const unsigned on = (pmask >> (4 * I)) & (pmask >> (4 * J)) & 15u;
+          if (on) {
+            d4_t c4 = {0.0, 0.0, 0.0, 0.0};
+            block_prod(Bt, I, on, Bt, J, on, NS, true, li, lk, c4);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Dn[(I * SB + lk + 4 * g) * LDT + J * SB + li] += c4[g];
+          }
+        }
+    STAMP(26);
     {
       const int r = t & 63, q = t >> 6;
       double sacc = 0.0;
@@ -648,37 +763,14 @@ __global__ __launch_bounds__(256) void k_chol_band(const double* __restrict__ S,
       for (int c = 0; c < 16; ++c) sacc += Bt[r * LDT + 16 * q + c] * yv[16 * q + c];
       part[q][r] = sacc;
     }
-    if (wave != 1) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int r = wr * 32 + i * 16 + (lane >> 4) + 4 * g;
-            const int c = wc * 32 + j * 16 + (lane & 15);
-            double v = (r == c) ? 1.0 : 0.0;
-            if (r < nb1 && c < nb1) v = (c <= r) ? acc[i][j][g] : 0.0;
-            D[r * LDT + c] = v;
-          }
-    } else {
-      // the quadrant above the diagonal of the padded block: zeros
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int r = i * 16 + (lane >> 4) + 4 * g;
-            const int c = 32 + j * 16 + (lane & 15);
-            D[r * LDT + c] = 0.0;
-          }
-    }
     __syncthreads();
-    if (t < NB) tv[t] = e_next - ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t]));
-    // (diag_core opens with a workgroup barrier: D and tv are visible to every wave after it)
+    STAMP(27);
+    if (t < NB) tv[t] = en[t] - ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t]));
+    // (diag_core opens with a workgroup barrier: Dn and tv are visible to every wave after it)
   }
   __syncthreads();
+  STAMP_GATE(1);
+  STAMP(28);
   // backward substitution, last panel first: x_k = inv(L_kk)^T (y_k - P_k^T x_{k+1}); yv holds y of the
   // last panel already.  Thread (col = t & 63, rq = t >> 6) sums rows rq, rq+4, ... of its column.
   const int col = t & 63, rq = t >> 6;
@@ -730,6 +822,307 @@ __global__ __launch_bounds__(256) void k_chol_band(const double* __restrict__ S,
     }
     __syncthreads();
   }
+  STAMP(29);
+}
+
+// ---- band path, parallel form: block cyclic reduction -----------------------------------------
+// The same band (no non-zero further than 64 places from the diagonal) makes S block tridiagonal in
+// 64 x 64 blocks: diagonal blocks D_i and couplings B_i = S(block i+1, block i).  Eliminating every
+// second block at once leaves a block tridiagonal system in the remaining half - a Cholesky
+// factorisation in odd-even order - so the chain of n/64 dependent diagonal factorisations becomes
+// log2(n/64) rounds, each factoring its blocks on separate compute units.  At stride s the active
+// blocks are 0, s, 2s, ...; block i = j s with odd j is eliminated:
+//     D_i = L_i L_i^T,  y_i = inv(L_i) e_i,
+//     P_u = S(u, i) inv(L_i)^T  (u = i - s),   P_d = S(d, i) inv(L_i)^T  (d = i + s),
+// and the remaining blocks take
+//     D_u -= P_u P_u^T,  D_d -= P_d P_d^T,  e_u -= P_u y_i,  e_d -= P_d y_i,  S(d, u) = -P_d P_u^T.
+// Backwards, last round first:  x_i = inv(L_i)^T (y_i - P_u^T x_u - P_d^T x_d).
+// Workspace per block: D (then the inverse of its factor), B, P_u, P_d (64 x 64 each), e (64).
+
+// c += sign * A[block row I, cols] B[block row J, cols]^T over block columns kb < kb_end.  With
+// trans_a the first operand is read transposed: A^T[block row I] from a tile stored [k][row].
+__device__ __forceinline__ void tile_mma(const double* __restrict__ A, bool trans_a, int I,
+                                         const double* __restrict__ B, int J, int kb_end, bool negate,
+                                         int li, int lk, d4_t& c) {
+  constexpr int NS = NB / SB;
+  double av[NS][4], bv[NS][4];
+#pragma unroll
+  for (int kb = 0; kb < NS; ++kb)
+    if (kb < kb_end) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kcol = kb * SB + 4 * q + lk;
+        const double a = trans_a ? A[kcol * LDT + I * SB + li] : A[(I * SB + li) * LDT + kcol];
+        av[kb][q] = negate ? -a : a;
+        bv[kb][q] = B[(J * SB + li) * LDT + kcol];
+      }
+    }
+#pragma unroll
+  for (int kb = 0; kb < NS; ++kb)
+    if (kb < kb_end) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kb][q], bv[kb][q], c, 0, 0, 0);
+    }
+}
+
+// 64 x 64 row-major tile in global memory -> LDS tile with row stride LDT (all 256 threads)
+__device__ __forceinline__ void tile_to_lds(const double* __restrict__ g, double* __restrict__ l, int t) {
+  double v[NB * NB / 256];
+#pragma unroll
+  for (int it = 0; it < NB * NB / 256; ++it) v[it] = g[t + 256 * it];
+#pragma unroll
+  for (int it = 0; it < NB * NB / 256; ++it) {
+    const int idx = t + 256 * it;
+    l[(idx / NB) * LDT + idx % NB] = v[it];
+  }
+}
+
+// S -> block tridiagonal form: D_i (lower triangle, identity past the matrix edge), B_i, e_i
+__global__ __launch_bounds__(256) void k_bcr_extract(const double* __restrict__ S, int n, int np,
+                                                     double* __restrict__ Dk, double* __restrict__ Bk,
+                                                     double* __restrict__ ek) {
+  const int i = blockIdx.x, t = threadIdx.x;
+  const int k0 = i * NB, k1 = k0 + NB;
+  const int nb = (n - k0) < NB ? (n - k0) : NB;
+  const int nb1 = (n - k1) < NB ? (n - k1) : NB;  // <= 0 for the last block
+  double vd[NB * NB / 256], vb[NB * NB / 256];
+#pragma unroll
+  for (int it = 0; it < NB * NB / 256; ++it) {
+    const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
+    vd[it] = (r == c) ? 1.0 : 0.0;
+    if (r < nb && c < nb) vd[it] = (c <= r) ? S[(int64_t)(k0 + r) * n + k0 + c] : 0.0;
+    vb[it] = (r < nb1) ? S[(int64_t)(k1 + r) * n + k0 + c] : 0.0;
+  }
+#pragma unroll
+  for (int it = 0; it < NB * NB / 256; ++it) {
+    Dk[(int64_t)i * NB * NB + t + 256 * it] = vd[it];
+    Bk[(int64_t)i * NB * NB + t + 256 * it] = vb[it];
+  }
+  if (t < NB) ek[k0 + t] = t < nb ? S[(int64_t)n * n + k0 + t] : 0.0;
+}
+
+// one workgroup per eliminated block: j = j0 + 2 blockIdx, i = j s
+__global__ __launch_bounds__(256) void k_bcr_eliminate(int n, int np, int s, int j0, double* __restrict__ Dk,
+                                                       const double* __restrict__ Bk, double* __restrict__ Pu,
+                                                       double* __restrict__ Pd, double* __restrict__ ek,
+                                                       int32_t* __restrict__ info) {
+  constexpr int NS = NB / SB;
+  __shared__ double L[NB * LDT];
+  __shared__ double X[NB * LDT];
+  __shared__ double Bu[NB * LDT];  // S(i, u) = coupling stored with block u; read transposed
+  __shared__ double Bd[NB * LDT];  // S(d, i) = coupling stored with block i
+  __shared__ double ev[NB];
+  __shared__ double part[4][NB];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const int i = (j0 + 2 * (int)blockIdx.x) * s;
+  const bool has_u = i - s >= 0, has_d = i + s < np;
+  const int k0 = i * NB;
+  const int nb = (n - k0) < NB ? (n - k0) : NB;
+  double* Di = Dk + (int64_t)i * NB * NB;
+  tile_to_lds(Di, L, t);
+  for (int idx = t; idx < NB * LDT; idx += 256) X[idx] = 0.0;
+  // the coupling tiles and the right-hand side arrive while the first block columns are factored
+  auto fetch = [&](int kk, int tt) {
+    if (kk > 1) return;
+    const bool on = kk == 0 ? has_u : has_d;
+    if (on) {
+      const double* g = Bk + (int64_t)(kk == 0 ? i - s : i) * NB * NB;
+      double* l = kk == 0 ? Bu : Bd;
+      double v[NB * NB / 128];
+#pragma unroll
+      for (int it = 0; it < NB * NB / 128; ++it) v[it] = g[tt + 128 * it];
+#pragma unroll
+      for (int it = 0; it < NB * NB / 128; ++it) {
+        const int idx = tt + 128 * it;
+        l[(idx / NB) * LDT + idx % NB] = v[it];
+      }
+    }
+    if (kk == 0 && tt < NB) ev[tt] = ek[k0 + tt];
+  };
+  diag_core(L, X, nullptr, n, k0, nb, Di, info, fetch);
+  // y_i = inv(L_i) e_i
+  {
+    const int r = t & 63, q = t >> 6;
+    double sacc = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) sacc += X[r * LDT + 16 * q + c] * ev[16 * q + c];
+    part[q][r] = sacc;
+  }
+  __syncthreads();
+  if (t < NB) ek[k0 + t] = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+  // P_u = S(u, i) inv(L_i)^T = Bu^T X^T,  P_d = Bd X^T.  Wave w owns the blocks (I, (w - I) mod 4);
+  // inv(L_i) is lower triangular: block column kb contributes to block (I, J) only for kb <= J.
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    if (side == 0 ? !has_u : !has_d) continue;
+    const double* Bsrc = side == 0 ? Bu : Bd;
+    double* Pout = (side == 0 ? Pu : Pd) + (int64_t)i * NB * NB;
+#pragma unroll
+    for (int I = 0; I < NS; ++I) {
+      const int J = (wave - I) & 3;
+      d4_t c4 = {0.0, 0.0, 0.0, 0.0};
+      tile_mma(Bsrc, side == 0, I, X, J, J + 1, false, li, lk, c4);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) Pout[(I * SB + lk + 4 * g) * NB + J * SB + li] = c4[g];
+    }
+  }
+}
+
+// one workgroup per (remaining block, task): j = 2 (blockIdx >> 1), i = j s.  Task 0 updates D_i and
+// e_i from the eliminated neighbours on both sides; task 1 forms the new coupling S(i + 2s, i).
+__global__ __launch_bounds__(256) void k_bcr_update(int n, int np, int s, double* __restrict__ Dk,
+                                                    double* __restrict__ Bk, const double* __restrict__ Pu,
+                                                    const double* __restrict__ Pd, double* __restrict__ ek) {
+  constexpr int NS = NB / SB;
+  __shared__ double Ta[NB * LDT];
+  __shared__ double Tb[NB * LDT];
+  __shared__ double ya[NB], yb[NB];
+  __shared__ double part[4][NB];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const int i = 2 * ((int)blockIdx.x >> 1) * s;
+  const int task = blockIdx.x & 1;
+  const int o1 = i - s, o2 = i + s;
+  const bool has1 = o1 >= 0, has2 = o2 < np;
+  if (task == 1) {
+    // S(i + 2s, i) = -P_d[o2] P_u[o2]^T
+    if (!has2 || i + 2 * s >= np) return;
+    tile_to_lds(Pd + (int64_t)o2 * NB * NB, Ta, t);
+    tile_to_lds(Pu + (int64_t)o2 * NB * NB, Tb, t);
+    __syncthreads();
+    double* Bout = Bk + (int64_t)i * NB * NB;
+#pragma unroll
+    for (int I = 0; I < NS; ++I) {
+      const int J = (wave - I) & 3;
+      d4_t c4 = {0.0, 0.0, 0.0, 0.0};
+      tile_mma(Ta, false, I, Tb, J, NS, true, li, lk, c4);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) Bout[(I * SB + lk + 4 * g) * NB + J * SB + li] = c4[g];
+    }
+    return;
+  }
+  if (!has1 && !has2) return;
+  // zero tiles stand in for a missing neighbour
+  if (has1) {
+    tile_to_lds(Pd + (int64_t)o1 * NB * NB, Ta, t);
+  } else {
+    for (int idx = t; idx < NB * LDT; idx += 256) Ta[idx] = 0.0;
+  }
+  if (has2) {
+    tile_to_lds(Pu + (int64_t)o2 * NB * NB, Tb, t);
+  } else {
+    for (int idx = t; idx < NB * LDT; idx += 256) Tb[idx] = 0.0;
+  }
+  if (t < NB) {
+    ya[t] = has1 ? ek[o1 * NB + t] : 0.0;
+    yb[t] = has2 ? ek[o2 * NB + t] : 0.0;
+  }
+  __syncthreads();
+  double* Di = Dk + (int64_t)i * NB * NB;
+  // lower blocks (I, J), J <= I; wave w owns those with (I + J) mod 4 = w
+#pragma unroll
+  for (int I = 0; I < NS; ++I)
+#pragma unroll
+    for (int J = 0; J <= I; ++J)
+      if (((I + J) & 3) == wave) {
+        d4_t c4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) c4[g] = Di[(I * SB + lk + 4 * g) * NB + J * SB + li];
+        if (has1) tile_mma(Ta, false, I, Ta, J, NS, true, li, lk, c4);
+        if (has2) tile_mma(Tb, false, I, Tb, J, NS, true, li, lk, c4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Di[(I * SB + lk + 4 * g) * NB + J * SB + li] = c4[g];
+      }
+  // e_i -= P_d[o1] y_o1 + P_u[o2] y_o2
+  {
+    const int r = t & 63, q = t >> 6;
+    double sacc = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      sacc += Ta[r * LDT + 16 * q + c] * ya[16 * q + c] + Tb[r * LDT + 16 * q + c] * yb[16 * q + c];
+    part[q][r] = sacc;
+  }
+  __syncthreads();
+  if (t < NB) ek[i * NB + t] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+}
+
+// x_i = inv(L_i)^T (y_i - P_u^T x_u - P_d^T x_d) for the blocks eliminated at stride s
+__global__ __launch_bounds__(256) void k_bcr_back(int n, int np, int s, int j0, const double* __restrict__ Dk,
+                                                  const double* __restrict__ Pu, const double* __restrict__ Pd,
+                                                  double* __restrict__ ek, double* __restrict__ x_out) {
+  __shared__ double xu[NB], xd[NB], zv[NB];
+  __shared__ double part[4][NB];
+  const int t = threadIdx.x;
+  const int col = t & 63, rq = t >> 6;
+  const int i = (j0 + 2 * (int)blockIdx.x) * s;
+  const bool has_u = i - s >= 0, has_d = i + s < np;
+  const int k0 = i * NB;
+  const int nb = (n - k0) < NB ? (n - k0) : NB;
+  // thread (col, rq) sums rows rq, rq + 4, ... of its column: all three tiles are fetched up front
+  double pu[NB / 4], pd[NB / 4], xi[NB / 4];
+#pragma unroll
+  for (int q = 0; q < NB / 4; ++q) {
+    const int r = rq + 4 * q;
+    pu[q] = has_u ? Pu[(int64_t)i * NB * NB + r * NB + col] : 0.0;
+    pd[q] = has_d ? Pd[(int64_t)i * NB * NB + r * NB + col] : 0.0;
+    xi[q] = col <= r ? Dk[(int64_t)i * NB * NB + r * NB + col] : 0.0;  // lower triangle holds inv(L_i)
+  }
+  if (t < NB) {
+    xu[t] = has_u ? ek[(i - s) * NB + t] : 0.0;
+    xd[t] = has_d ? ek[(i + s) * NB + t] : 0.0;
+  }
+  __syncthreads();
+  double sacc = 0.0;
+#pragma unroll
+  for (int q = 0; q < NB / 4; ++q) sacc += pu[q] * xu[rq + 4 * q] + pd[q] * xd[rq + 4 * q];
+  part[rq][col] = sacc;
+  __syncthreads();
+  if (t < NB) zv[t] = ek[k0 + t] - ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t]));
+  __syncthreads();
+  sacc = 0.0;
+#pragma unroll
+  for (int q = 0; q < NB / 4; ++q) sacc += xi[q] * zv[rq + 4 * q];
+  part[rq][col] = sacc;
+  __syncthreads();
+  if (t < NB) {
+    const double xk = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+    ek[k0 + t] = xk;
+    if (t < nb) x_out[k0 + t] = xk;
+  }
+}
+
+static int launch_solve_bcr(const double* S, int n, double* da, void* ws, int32_t* info, hipStream_t st) {
+  const int np = (n + NB - 1) / NB;
+  double* Dk = static_cast<double*>(ws);
+  double* Bk = Dk + (int64_t)np * NB * NB;
+  double* Pu = Bk + (int64_t)np * NB * NB;
+  double* Pd = Pu + (int64_t)np * NB * NB;
+  double* ek = Pd + (int64_t)np * NB * NB;
+  hipLaunchKernelGGL(k_bcr_extract, dim3(np), dim3(256), 0, st, S, n, np, Dk, Bk, ek);
+  int s = 1;
+  for (; s < np; s *= 2) {
+    const int m = (np + s - 1) / s;  // active blocks 0, s, 2s, ...
+    hipLaunchKernelGGL(k_bcr_eliminate, dim3(m / 2), dim3(256), 0, st, n, np, s, 1, Dk, Bk, Pu, Pd, ek, info);
+    hipLaunchKernelGGL(k_bcr_update, dim3(2 * ((m + 1) / 2)), dim3(256), 0, st, n, np, s, Dk, Bk, Pu, Pd, ek);
+  }
+  // block 0 is what is left: no neighbours at this stride
+  hipLaunchKernelGGL(k_bcr_eliminate, dim3(1), dim3(256), 0, st, n, np, s, 0, Dk, Bk, Pu, Pd, ek, info);
+  hipLaunchKernelGGL(k_bcr_back, dim3(1), dim3(256), 0, st, n, np, s, 0, Dk, Pu, Pd, ek, da);
+  for (s /= 2; s >= 1; s /= 2) {
+    const int m = (np + s - 1) / s;
+    hipLaunchKernelGGL(k_bcr_back, dim3(m / 2), dim3(256), 0, st, n, np, s, 1, Dk, Pu, Pd, ek, da);
+  }
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_hip_error(err, "cyclic reduction launches");
+    return SFM_BA_EHIP;
+  }
+  return SFM_BA_OK;
 }
 
 __global__ void k_copy_row(const double* __restrict__ src, double* __restrict__ dst, int n) {
@@ -750,6 +1143,7 @@ int launch_solve_reduced(double* S, int n, int half_bandwidth, double* da, void*
     return SFM_BA_EHIP;
   }
   if (half_bandwidth >= 0 && half_bandwidth <= NB) {
+    if (np >= 4) return launch_solve_bcr(S, n, da, ws, info, st);
     double* p_ws = reinterpret_cast<double*>(zflags);
     hipLaunchKernelGGL(k_chol_band, dim3(1), dim3(256), 0, st, S, n, invL, p_ws, y, da, info);
     err = hipGetLastError();
