@@ -13,7 +13,8 @@ constexpr int kGroupSlots = 256;   // observations handled by one workgroup of t
 constexpr int kCamChunk = 1024;    // observations per per-camera work item
 constexpr int kCamThreads = 128;   // threads of a per-camera work item
 constexpr int kPairChunk = 512;   // (obs, obs) entries per camera-pair work item (one wave each)
-constexpr int kPairPad = 64;        // valid records / T rows kept behind the last entry
+constexpr int kPairPad = 64;
+constexpr int kPairPartStride = 56;  // doubles per partial result of a split block: 7x7 block + e_j        // valid records / T rows kept behind the last entry
 
 struct PairEntry {
   int32_t obs_a;  // observation (caller order) of the block's row camera j

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void k_point(
     const int32_t* __restrict__ perm, const int32_t* __restrict__ tp_ptr,
     const int32_t* __restrict__ pair_entry,
     const double* __restrict__ B, const double* __restrict__ xt, const double* __restrict__ xpred,
-    const double* __restrict__ wgt, double mu, double* __restrict__ Vinv,
+    const double* __restrict__ wgt, double mu, int fold_u, double* __restrict__ Vinv,
     double* __restrict__ eps_b, double* __restrict__ g, double* __restrict__ T) {
   __shared__ double sBp[kGroupSlots * 6];
   __shared__ double sCon[kGroupSlots * 9];
@@ -278,6 +278,7 @@ __global__ __launch_bounds__(256) void k_point(
     for (int s = sPtr[t]; s < sPtr[t + 1]; ++s) sLp[s - s0] = t;
 
   double bp[6], we[2];
+  double w00 = 1.0, w01 = 0.0, w10 = 0.0, w11 = 1.0;
   int pos = 0;
   if (t < ns) {
     pos = perm[s0 + t];
@@ -286,7 +287,6 @@ __global__ __launch_bounds__(256) void k_point(
     const double bb[6] = {b01.x, b01.y, b23.x, b23.y, b45.x, b45.y};
     const double2 xa = ld2(xt + 2 * (int64_t)pos), xb = ld2(xpred + 2 * (int64_t)pos);
     const double e0 = xa.x - xb.x, e1 = xa.y - xb.y;
-    double w00 = 1.0, w01 = 0.0, w10 = 0.0, w11 = 1.0;
     if (wgt) {
       const double* wp = wgt + 4 * (int64_t)pos;
       w00 = wp[0]; w01 = wp[1]; w10 = wp[2]; w11 = wp[3];
@@ -363,8 +363,15 @@ __global__ __launch_bounds__(256) void k_point(
     for (int b = a; b < k; ++b, ++ts) {
       const double* q = sBp + 6 * (first + b);
       double* o = T + 4 * (int64_t)pair_entry[ts];  // row of T = position of the pair's entry
-      st2(o, h00 * q[0] + h01 * q[1] + h02 * q[2], h00 * q[3] + h01 * q[4] + h02 * q[5]);
-      st2(o + 2, h10 * q[0] + h11 * q[1] + h12 * q[2], h10 * q[3] + h11 * q[4] + h12 * q[5]);
+      double t00 = h00 * q[0] + h01 * q[1] + h02 * q[2], t01 = h00 * q[3] + h01 * q[4] + h02 * q[5];
+      double t10 = h10 * q[0] + h11 * q[1] + h12 * q[2], t11 = h10 * q[3] + h11 * q[4] + h12 * q[5];
+      if (fold_u && b == a) {
+        // the observation's own pair also carries its term of U_j = sum A^T w A: the camera-pair
+        // kernel then produces U_j - sum Y W^T for the diagonal blocks by itself
+        t00 -= w00; t01 -= w01; t10 -= w10; t11 -= w11;
+      }
+      st2(o, t00, t01);
+      st2(o + 2, t10, t11);
     }
   }
 }
@@ -516,9 +523,11 @@ __global__ __launch_bounds__(64) void k_pair_blocks(
     int n_items, const int32_t* __restrict__ pit_blk, const int32_t* __restrict__ pit_beg,
     const int32_t* __restrict__ pit_end, const int32_t* __restrict__ pit_part,
     const int32_t* __restrict__ blk_j, const int32_t* __restrict__ blk_k,
-    const PairEntry* __restrict__ ent, const double* __restrict__ A, const double* __restrict__ T,
-    const double* __restrict__ cam_part, const int32_t* __restrict__ cam_item_ptr, double mu_u, int m,
-    double* __restrict__ S, double* __restrict__ spart) {
+    const PairEntry* __restrict__ ent, const double* __restrict__ A, const double* __restrict__ gT,
+    unsigned t_off, int fold_u, const double* __restrict__ cam_part, const int32_t* __restrict__ cam_item_ptr,
+    double mu_u, int m, double* __restrict__ S, double* __restrict__ e_out, double* __restrict__ spart) {
+  // gT: start of the buffer that holds g [N][2] (at byte 0) and T [pairs][4] (at byte t_off).
+  // fold_u: the self pairs carry U_j (see k_point) and the diagonal blocks also sum e_j = A^T g
   // one LDS object for row images and record slots
   __shared__ __attribute__((aligned(16))) double lds[(kPairRing * kPairImgB + kPairERing * 1024) / 8];
   double* const rows = lds;
@@ -533,6 +542,9 @@ __global__ __launch_bounds__(64) void k_pair_blocks(
   const int g = lane >> 2, h = lane & 3;
   const int beg = __builtin_amdgcn_readfirstlane(pit_beg[item]);
   const int end = __builtin_amdgcn_readfirstlane(pit_end[item]);
+  const int blk = __builtin_amdgcn_readfirstlane(pit_blk[item]);
+  const int bj = __builtin_amdgcn_readfirstlane(blk_j[blk]), bk = __builtin_amdgcn_readfirstlane(blk_k[blk]);
+  const bool with_e = fold_u && bj == bk;  // every entry of a diagonal block pairs an observation with itself
   const int nsteps = (end - beg + kPairStep - 1) / kPairStep;
   const int last_base = beg + kPairStep * (nsteps - 1);
   // row pieces: a 16-entry row block is 112 pieces of 16 bytes; this lane carries piece `lane`
@@ -556,9 +568,13 @@ __global__ __launch_bounds__(64) void k_pair_blocks(
     dma16(A, 112u * (unsigned)ea.y + 16u * c0, base + 2048);
     dma16(A, 112u * (unsigned)eb.y + 16u * c1, base + 2048 + 1024);
     const int i0 = min(beg + kPairStep * q, last_base);
-    dma16(T, 32u * (unsigned)(i0 + ((lane >> 1) & 15)) + 16u * (lane & 1), base + 4096);
+    // lanes 0..31: the 16 T rows; lanes 32..47 of a diagonal block: g of the step's 16 observations
+    unsigned off = t_off + 32u * (unsigned)(i0 + ((lane >> 1) & 15)) + 16u * (lane & 1);
+    if (with_e && lane >= 32 && lane < 48) off = 16u * (unsigned)er[2 * (lane - 32)];
+    dma16(gT, off, base + 4096);
   };
   double acc0[7] = {0, 0, 0, 0, 0, 0, 0}, acc1[7] = {0, 0, 0, 0, 0, 0, 0};
+  double e0 = 0.0, e1 = 0.0;
   auto consume = [&](int q) {
     const int i0 = beg + kPairStep * q;
     const double* ba = rows + (kPairImgB / 8) * (q % kPairRing);
@@ -570,6 +586,12 @@ __global__ __launch_bounds__(64) void k_pair_blocks(
     const double b10 = bb[14 * g + 7 + 2 * h], b11 = bb[14 * g + 8 + 2 * h];
     const double p00 = t0.x * b0.x + t0.y * b10, p10 = t1.x * b0.x + t1.y * b10;
     const double p01 = t0.x * b0.y + t0.y * b11, p11 = t1.x * b0.y + t1.y * b11;
+    if (with_e) {
+      double2 gv = ld2(ba + 512 + 64 + 2 * g);
+      if (i0 + g >= end) gv = make_double2(0.0, 0.0);
+      e0 = fma(b10, gv.y, fma(b0.x, gv.x, e0));
+      e1 = fma(b11, gv.y, fma(b0.y, gv.x, e1));
+    }
     double a[14];
 #pragma unroll
     for (int q2 = 0; q2 < 7; ++q2) {
@@ -610,21 +632,38 @@ __global__ __launch_bounds__(64) void k_pair_blocks(
     acc0[r] = v;
     acc1[r] = w;
   }
+  if (with_e) {
+#pragma unroll
+    for (int sft = 4; sft < 64; sft <<= 1) {
+      e0 += __shfl_xor(e0, sft);
+      e1 += __shfl_xor(e1, sft);
+    }
+  }
   if (g != 0) return;
   const int part = pit_part[item];
   const int ncol = h < 3 ? 2 : 1;
   if (part >= 0) {
-    double* o = spart + (int64_t)part * 49;
+    double* o = spart + (int64_t)part * kPairPartStride;
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
       o[7 * r + 2 * h] = acc0[r];
       if (ncol == 2) o[7 * r + 2 * h + 1] = acc1[r];
     }
+    if (with_e) {
+      o[49 + 2 * h] = e0;
+      if (ncol == 2) o[49 + 2 * h + 1] = e1;
+    }
     return;
   }
-  const int b = pit_blk[item];
-  const int j = blk_j[b], k = blk_k[b];
+  const int j = bj, k = bk;
   const int64_t ld = 7 * (int64_t)m;
+  if (with_e) {
+    for (int cs = 0; cs < ncol; ++cs) {
+      const double ev = cs == 0 ? e0 : e1;
+      S[ld * ld + 7 * j + 2 * h + cs] = ev;
+      if (e_out) e_out[7 * j + 2 * h + cs] = ev;
+    }
+  }
   for (int cs = 0; cs < ncol; ++cs) {
     const int c = 2 * h + cs;
 #pragma unroll
@@ -635,7 +674,8 @@ __global__ __launch_bounds__(64) void k_pair_blocks(
         const int lo = r < c ? r : c, hi = r < c ? c : r;
         const int idx = lo * 7 - lo * (lo - 1) / 2 + (hi - lo);
         double u = 0.0;
-        for (int it = cam_item_ptr[j]; it < cam_item_ptr[j + 1]; ++it) u += cam_part[(int64_t)it * SFM_BA_CAM_RED + idx];
+        if (!fold_u)
+          for (int it = cam_item_ptr[j]; it < cam_item_ptr[j + 1]; ++it) u += cam_part[(int64_t)it * SFM_BA_CAM_RED + idx];
         if (r == c) u += mu_u;
         S[(7 * (int64_t)j + r) * ld + 7 * k + c] = u - av;
       } else {
@@ -652,21 +692,29 @@ __global__ __launch_bounds__(64) void k_pair_finish(
     const int32_t* __restrict__ mb_cnt, const int32_t* __restrict__ blk_j,
     const int32_t* __restrict__ blk_k, const double* __restrict__ spart,
     const double* __restrict__ cam_part, const int32_t* __restrict__ cam_item_ptr, double mu_u, int m,
-    double* __restrict__ S) {
+    int fold_u, double* __restrict__ S, double* __restrict__ e_out) {
   const int t = threadIdx.x;
-  if (t >= 49) return;
+  if (t >= kPairPartStride) return;
   const int b = mb_blk[blockIdx.x];
   const int p0 = mb_part[blockIdx.x], cnt = mb_cnt[blockIdx.x];
-  double a = 0.0;
-  for (int i = 0; i < cnt; ++i) a += spart[(int64_t)(p0 + i) * 49 + t];
   const int j = blk_j[b], k = blk_k[b];
-  const int r = t / 7, c = t % 7;
+  if (t >= 49 && !(fold_u && j == k)) return;
+  double a = 0.0;
+  for (int i = 0; i < cnt; ++i) a += spart[(int64_t)(p0 + i) * kPairPartStride + t];
   const int64_t ld = 7 * (int64_t)m;
+  if (t >= 49) {
+    // e_j of a diagonal block (slots 49..55 of its partials)
+    S[ld * ld + 7 * j + (t - 49)] = a;
+    if (e_out) e_out[7 * j + (t - 49)] = a;
+    return;
+  }
+  const int r = t / 7, c = t % 7;
   if (j == k) {
     const int lo = r < c ? r : c, hi = r < c ? c : r;
     const int idx = lo * 7 - lo * (lo - 1) / 2 + (hi - lo);
     double u = 0.0;
-    for (int it = cam_item_ptr[j]; it < cam_item_ptr[j + 1]; ++it) u += cam_part[(int64_t)it * SFM_BA_CAM_RED + idx];
+    if (!fold_u)
+      for (int it = cam_item_ptr[j]; it < cam_item_ptr[j + 1]; ++it) u += cam_part[(int64_t)it * SFM_BA_CAM_RED + idx];
     if (r == c) u += mu_u;
     S[(7 * (int64_t)j + r) * ld + 7 * k + c] = u - a;
   } else {
@@ -935,16 +983,19 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
   double* T = reinterpret_cast<double*>(base + p->ws_T);
   double* campart = reinterpret_cast<double*>(base + p->ws_campart);
   double* spart = reinterpret_cast<double*>(base + p->ws_spart);
+  // Callers that want none of the per-camera by-products (U, eps_a, the all-reduce records) get
+  // them folded into the camera-pair kernel: no separate pass over A.
+  const int fold_u = (S && !U && !eps_a && !cam_red) ? 1 : 0;
   if (p->n_groups > 0) {
     {
     ProfScope ps(KID_POINT, st);
     hipLaunchKernelGGL(k_point, dim3(p->n_groups), dim3(256), 0, st, p->d_grp_pt, p->d_pt_ptr, p->d_perm,
-                       p->d_tp_ptr, p->d_pair_entry, B, xt, xp, w, mu, Vinv, eps_b, g, T);
+                       p->d_tp_ptr, p->d_pair_entry, B, xt, xp, w, mu, fold_u, Vinv, eps_b, g, T);
   }
     int rc = check_launch("k_point");
     if (rc) return rc;
   }
-  if (p->n_items > 0) {
+  if (p->n_items > 0 && !fold_u) {
     {
     ProfScope ps(KID_CAMERA_ITEMS, st);
     hipLaunchKernelGGL(k_camera_items, dim3(p->n_items), dim3(kCamThreads), 0, st, p->d_item_beg,
@@ -953,19 +1004,23 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
     int rc = check_launch("k_camera_items");
     if (rc) return rc;
   }
-  {
-    ProfScope ps(KID_CAMERA_FINISH, st);
-    hipLaunchKernelGGL(k_camera_finish, dim3(p->m), dim3(64), 0, st, p->d_cam_item_ptr, campart, p->m, mu_u, S,
-                     e, U, eps_a, cam_red);
+  int rc = SFM_BA_OK;
+  if (!fold_u) {
+    {
+      ProfScope ps(KID_CAMERA_FINISH, st);
+      hipLaunchKernelGGL(k_camera_finish, dim3(p->m), dim3(64), 0, st, p->d_cam_item_ptr, campart, p->m, mu_u, S,
+                         e, U, eps_a, cam_red);
+    }
+    rc = check_launch("k_camera_finish");
+    if (rc) return rc;
   }
-  int rc = check_launch("k_camera_finish");
-  if (rc) return rc;
   if (p->n_pair_items > 0 && S) {
     {
     ProfScope ps(KID_PAIR_BLOCKS, st);
     hipLaunchKernelGGL(k_pair_blocks, dim3(p->n_pair_items), dim3(64), 0, st, p->n_pair_items,
                        p->d_pit_blk, p->d_pit_beg, p->d_pit_end, p->d_pit_part, p->d_blk_j, p->d_blk_k,
-                       p->d_entries, A, T, campart, p->d_cam_item_ptr, mu_u, p->m, S, spart);
+                       p->d_entries, A, g, (unsigned)(p->ws_T - p->ws_g), fold_u, campart, p->d_cam_item_ptr, mu_u,
+                       p->m, S, e, spart);
   }
     rc = check_launch("k_pair_blocks");
     if (rc) return rc;
@@ -973,7 +1028,8 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
       {
     ProfScope ps(KID_PAIR_FINISH, st);
     hipLaunchKernelGGL(k_pair_finish, dim3(p->n_multi), dim3(64), 0, st, p->d_mb_blk, p->d_mb_part,
-                         p->d_mb_cnt, p->d_blk_j, p->d_blk_k, spart, campart, p->d_cam_item_ptr, mu_u, p->m, S);
+                         p->d_mb_cnt, p->d_blk_j, p->d_blk_k, spart, campart, p->d_cam_item_ptr, mu_u, p->m,
+                         fold_u, S, e);
   }
       rc = check_launch("k_pair_finish");
       if (rc) return rc;

@@ -128,7 +128,8 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
       in_group += k;
       tp_ptr[i] = (int32_t)pairs;
       pairs += (int64_t)k * (k + 1) / 2;
-      if ((pairs + kPairPad) * 32 >= (int64_t(1) << 32)) {  // 32-bit byte offsets into T
+      // 32-bit byte offsets into T, counted from the start of g that precedes it in the workspace
+      if (N * 16 + 256 + (pairs + kPairPad) * 32 >= (int64_t(1) << 32)) {
         delete p;
         return SFM_BA_ETOOBIG;
       }
@@ -263,7 +264,7 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   p->ws_campart = off;
   off = align256(off + (int64_t)std::max(p->n_items, 1) * SFM_BA_CAM_RED * (int64_t)sizeof(double));
   p->ws_spart = off;
-  off = align256(off + (int64_t)std::max(n_parts, 1) * 49 * (int64_t)sizeof(double));
+  off = align256(off + (int64_t)std::max(n_parts, 1) * kPairPartStride * (int64_t)sizeof(double));
   p->ws_total = off;
   *out = p;
   return SFM_BA_OK;

@@ -190,7 +190,9 @@ class DeviceProblem:
         _lib.check(self.lib.sfm_ba_jacobian(p(self.cam_blk), p(self.P), p(self.X), p(self.cam_idx), p(self.pt_idx),
                                             self.N, None, None, p(self.x_pred), _stream()))
 
-    def assemble(self, mu, weights=None, x_true=None, x_pred=None, A=None, B=None):
+    def assemble(self, mu, weights=None, x_true=None, x_pred=None, A=None, B=None, by_products=True):
+        """``by_products=False`` skips U and eps_a (the solve needs only S and e): the library then
+        folds the per-camera sums into the camera-pair kernel and makes one pass less over A."""
         p = _lib.ptr
         mu_u = 0.0 if self.sharded else mu
         n7 = self.n7
@@ -198,11 +200,13 @@ class DeviceProblem:
             # camera pairs without a shared point are not written by the kernels; the previous
             # factorisation left fill-in there (the narrow-band solve only reads S), and the
             # all-reduce of a sharded run left the other ranks' blocks there
-            self.sys[: n7 * n7].zero_()
+            # (row n7, the right-hand side, included: a shard need not observe every camera)
+            self.sys[: (n7 + 1) * n7].zero_()
         _lib.check(self.lib.sfm_ba_schur_assemble(
             self.plan.handle, p(self.A if A is None else A), p(self.B if B is None else B),
             p(self.x_true if x_true is None else x_true), p(self.x_pred if x_pred is None else x_pred),
-            p(weights), float(mu), float(mu_u), p(self.S), p(self.e), p(self.U), p(self.eps_a),
+            p(weights), float(mu), float(mu_u), p(self.S), p(self.e), p(self.U) if by_products else None,
+            p(self.eps_a) if by_products else None,
             p(self.V_inv), p(self.eps_b), None, p(self.workspace), _stream()))
         if self.sharded:
             import torch.distributed as dist
@@ -250,7 +254,7 @@ class DeviceProblem:
         mu = self.MU if mu is None else mu
         self.camera_prepare()
         self.jacobian()
-        self.assemble(mu)
+        self.assemble(mu, by_products=False)
         self.solve()
         self.back_substitute(update_points=True)
         self.update_cameras()
