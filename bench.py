@@ -25,16 +25,21 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
 FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector = matrix peak (datasheet)
 
 
-def algorithmic_bytes(N, n, m):
+def algorithmic_bytes(N, n, m, s_blocks):
     """Bytes per Gauss-Newton iteration a kernel group must move at minimum (fp64 values, int32
-    indices, A and B materialised as the reference's interface dictates)."""
+    indices, A and B materialised as the reference's interface dictates).  `s_blocks` = number of
+    7 x 7 blocks of S that hold a non-zero (camera pairs with a shared point, both triangles):
+    m * m when every pair of cameras shares a point, far fewer for banded visibility - only those
+    blocks are written."""
     return {
         "jacobian": 184 * N + 24 * n + 128 * m,
-        "assembly": 200 * N + 96 * n + 392 * m * m + 560 * m,
+        "assembly": 200 * N + 96 * n + 392 * s_blocks + 560 * m,
         "back_substitution": 168 * N + 120 * n + 56 * m,
     }
 
 
+# kernels that implement each stage (a kernel absent from a run's profile is skipped: the per-camera
+# kernels only run when a caller asks for U / eps_a)
 GROUPS = {
     "jacobian": ["k_jacobian"],
     "assembly": ["k_point", "k_camera_items", "k_camera_finish", "k_pair_blocks", "k_pair_finish"],
@@ -42,7 +47,18 @@ GROUPS = {
 }
 
 
-def cpu_baseline(workload, visibility, seed, sample_points=60000, iters=2):
+def measured_traffic(workload, visibility):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE with the
+    gfx950 read-side correction), or {} when none was taken for this workload."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(f"{workload}/{visibility}", {})
+    except (OSError, ValueError):
+        return {}
+
+
+def cpu_baseline(workload, visibility, seed, sample_points=100000, iters=4):
     """The numpy oracle (a port of the reference's algorithm) on a bounded sample of the workload."""
     import sfm_amd  # noqa: F401
     from sfm_amd import synthetic
@@ -154,29 +170,50 @@ def main():
 
     if rank == 0:
         per_kernel = {name: {"ms_avg": ms / cnt, "launches_per_step": cnt / args.steps} for name, (ms, cnt) in prof.items()}
-        alg = algorithmic_bytes(N_loc, n_loc, m)
+        s_blocks = 2 * prob.plan.n_blocks - m  # plan counts pairs j <= k
+        alg = algorithmic_bytes(N_loc, n_loc, m, s_blocks)
+        pmc = measured_traffic(args.workload, args.visibility) if world == 1 else {}
         groups = {}
         for g, names in GROUPS.items():
-            ms = sum(prof[nm][0] for nm in names if nm in prof) / args.steps
-            groups[g] = {"ms": ms, "bytes": alg[g], "GBps": alg[g] / (ms * 1e-3) / 1e9 if ms > 0 else None}
+            present = [nm for nm in names if nm in prof]
+            ms = sum(prof[nm][0] for nm in present) / args.steps
+            traffic = None
+            if present and all(nm in pmc for nm in present):
+                traffic = sum(pmc[nm]["bytes"] * prof[nm][1] / args.steps for nm in present)
+            groups[g] = {"ms": ms, "kernels": present, "bytes": alg[g],
+                         "GBps": alg[g] / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                         "traffic": traffic,
+                         "traffic_GBps": traffic / (ms * 1e-3) / 1e9 if traffic and ms > 0 else None}
+        # the dominant HBM-bound stage; its algorithmic bytes are defined per stage, so a stage that
+        # takes several kernels is priced as one unit (the slowest kernel inside it is named)
         dominant = max(groups, key=lambda g: groups[g]["ms"])
+        slowest = max(groups[dominant]["kernels"], key=lambda nm: prof[nm][0])
         roofline = {
             "bound": "hbm",
-            "kernel": dominant + " (" + "+".join(GROUPS[dominant]) + ")",
+            "kernel": f"{dominant} stage ({'+'.join(groups[dominant]['kernels'])}; slowest kernel {slowest}, "
+                      f"{prof[slowest][0] / prof[slowest][1] * 1e3:.1f} us per launch)",
             "achieved": groups[dominant]["GBps"],
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": groups[dominant]["GBps"] / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": groups[dominant]["traffic"],
             "groups": groups,
         }
         n7 = 7 * m
         solve_ms = prof.get("solve_reduced", (0.0, 1))[0] / args.steps
+        hb = prob.half_bandwidth
+        if hb <= 64:
+            # band Cholesky + two band substitutions
+            flops, path = n7 * (hb + 1.0) ** 2 + 4.0 * n7 * (hb + 1.0), "block cyclic reduction (band)"
+        else:
+            flops, path = n7 ** 3 / 3.0 + 2.0 * n7 * n7, "blocked Cholesky (dense)"
         solve = {
-            "bound": "fp64",
-            "flops": n7 ** 3 / 3.0 + 2.0 * n7 * n7,
+            "bound": "latency" if hb <= 64 else "mfma",
+            "path": path,
+            "half_bandwidth": hb,
+            "flops": flops,
             "ms": solve_ms,
-            "achieved": (n7 ** 3 / 3.0 + 2.0 * n7 * n7) / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else None,
+            "achieved": flops / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else None,
             "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s",
         }
@@ -199,6 +236,7 @@ def main():
                 "workload": f"{args.workload}: {m} cameras x {n_total} points x {N_total} observations, "
                             f"{args.visibility} visibility, seed {args.seed}, {n_per_gpu} points per GPU",
                 "cameras": m, "points": n_total, "observations": N_total, "visibility": args.visibility,
+                "nonzero_S_blocks": s_blocks,
                 "parallelism": "1 gpu" if world == 1 else f"point-id sharding x{world}, all-reduce of "
                                f"{packed_system_elements(m) * 8 / 1e6:.1f} MB per iteration",
             },

@@ -1,0 +1,18 @@
+#!/bin/bash
+# usage: scripts/gpu_evidence.sh <tag>   (on the GPU box, from the repo root)
+# Default bench line, the rocprofv3 kernel statistics of the same command, the two PMC traffic
+# passes, and one bench line per other workload.  Everything lands under gpurun_out/<tag>_*.
+set -o pipefail
+TAG=$1
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+export TMPDIR=/tmp
+cd $R
+timeout -k 10 300 python3 bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err || exit 1
+bash scripts/gpu_prof.sh ${TAG} > gpurun_out/${TAG}_prof_summary.txt || exit 2
+bash scripts/gpu_pmc.sh ${TAG}_fetch FETCH_SIZE $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_pmc_fetch.txt || exit 3
+bash scripts/gpu_pmc.sh ${TAG}_write WRITE_SIZE $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_pmc_write.txt || exit 4
+for W in "ladybug50 banded" "ladybug50 uniform" "c4_500x300k uniform" "venice1800 banded"; do
+  set -- $W
+  timeout -k 10 400 python3 bench.py --workload $1 --visibility $2 --no-cpu-baseline > gpurun_out/${TAG}_bench_$1_$2.json 2> gpurun_out/${TAG}_bench_$1_$2.err || exit 5
+done
+echo evidence done
