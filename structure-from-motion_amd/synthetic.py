@@ -139,6 +139,19 @@ def make_problem(
     T_gt = -np.einsum("mij,mj->mi", R_gt, C_gt)
 
     pt, cam = _views(rng, m, n, k, visibility)
+    p = observe_and_perturb(rng, K, R_gt, T_gt, X_gt, pt, cam, pixel_noise, point_perturb, rot_perturb,
+                            trans_perturb)
+    p.visibility = visibility
+    p.meta = dict(m=m, n=n, k=k, seed=seed, pixel_noise=pixel_noise)
+    return p
+
+
+def observe_and_perturb(rng, K, R_gt, T_gt, X_gt, pt, cam, pixel_noise=0.5, point_perturb=0.01,
+                        rot_perturb=0.002, trans_perturb=0.005) -> BAProblem:
+    """Observations and initial state for a given ground-truth geometry and visibility list
+    (``pt[i]`` is seen by ``cam[i]``): frame-major order, exact projections plus pixel noise
+    rounded to float32, ground truth perturbed as described in :func:`make_problem`."""
+    m, n = R_gt.shape[0], X_gt.shape[0]
     order = np.lexsort((pt, cam))  # frame-major, points ascending inside a frame
     pt, cam = pt[order], cam[order]
 
@@ -166,8 +179,6 @@ def make_problem(
         cam_idx=cam.astype(np.int32),
         pt_idx=pt.astype(np.int32),
         x_true=x_true,
-        visibility=visibility,
-        meta=dict(m=m, n=n, k=k, seed=seed, pixel_noise=pixel_noise),
     )
 
 

@@ -207,6 +207,26 @@ def test_outer_loop_50_iterations(ba):
     assert relerr(map_.X[:, :3], d["loop_X_final"]) < 1e-6
 
 
+@pytest.mark.parametrize("case", ["real_box", "real_boot"])
+def test_real_geometry_loop(ba, case):
+    """The reference's loop on the geometry of its own stage-1 outputs, 4 iterations (fixture and
+    bar as in tests/test_oracle_golden.py::test_real_geometry_loop: 2e-9 on the first iteration's
+    cost, 2e-8 afterwards, 1e-7 on the final state; the reference's own LU noise sets that floor)."""
+    d = load(case)
+    frames, map_ = frames_from_fixture(d)
+    ref = d["loop_costs"]
+    costs = np.asarray(ba.ba.optimize_using_BA(frames, map_, verbose=False, max_iter=len(ref)))
+    rel = np.abs(costs - ref) / ref
+    print(case, "relative cost differences:", rel)
+    assert rel[0] < 2e-9
+    assert rel.max() < 2e-8
+    assert relerr(np.stack([f.R for f in frames]), d["loop_R_final"]) < 1e-7
+    assert relerr(np.stack([f.T.reshape(3) for f in frames]), d["loop_T_final"]) < 1e-7
+    assert relerr(map_.X[:, :3], d["loop_X_final"]) < 1e-7
+    c = ba.ba.compute_reprojection_error_total(frames, map_)
+    assert abs(c - float(d["loop_cost_final"])) <= 2e-8 * float(d["loop_cost_final"])
+
+
 def test_optimize_pose_and_map(ba, capsys):
     d = load("ba_8x400")
     frames, map_ = frames_from_fixture(d)

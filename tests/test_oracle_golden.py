@@ -142,6 +142,27 @@ def test_outer_loop_50_iterations():
     assert relerr(map_.X[:, :3], d["loop_X_final"]) < 1e-6
 
 
+@pytest.mark.parametrize("case", ["real_box", "real_boot"])
+def test_real_geometry_loop(case):
+    """Cameras and point cloud of the reference's own stage-1 outputs (46 x 5189 x 38117 and
+    50 x 8123 x 53553), visibility by projection, the reference's loop stopped after 4 iterations
+    (tests/golden/make_real_geometry.py).  On this geometry the reference's iteration raises the
+    cost every step (181 -> 651 on `box`), cond(S) is ~1e9 and the LU solve of the reference is
+    itself ~1e-9 relative from the exact solution, so differences in summation order reach the cost
+    at the 1e-9 level and grow with the iteration count: measured 8e-10 (first) to 4e-9 (fourth).
+    Bar: 2e-9 on the first iteration, 2e-8 afterwards, 1e-7 on the final state."""
+    d = load(case)
+    frames, map_ = frames_from_fixture(d)
+    ref_costs = d["loop_costs"]
+    costs = np.asarray(orc.optimize_using_BA(frames, map_, max_iter=len(ref_costs)))
+    rel = np.abs(costs - ref_costs) / ref_costs
+    assert rel[0] < 2e-9
+    assert rel.max() < 2e-8
+    assert relerr(np.stack([f.R for f in frames]), d["loop_R_final"]) < 1e-7
+    assert relerr(np.stack([f.T.reshape(3) for f in frames]), d["loop_T_final"]) < 1e-7
+    assert relerr(map_.X[:, :3], d["loop_X_final"]) < 1e-7
+
+
 def test_error_cases():
     with open(os.path.join(GOLDEN, "errors.json")) as fh:
         cases = json.load(fh)
