@@ -1,0 +1,13 @@
+#!/bin/bash
+# usage: scripts/collect_evidence.sh <run tag> <round tag>   e.g. r01ev r01
+# Copies what scripts/gpu_evidence.sh left under gpurun_out/ into profiles/ and regenerates profiles/README.md.
+set -e
+RUN=$1; RT=$2
+cd "$(dirname "$0")/.."
+cp gpurun_out/prof_${RUN}/*/*kernel_stats.csv profiles/${RT}_c4_banded_kernel_stats.csv
+cp gpurun_out/${RUN}_prof_summary.txt profiles/${RT}_c4_banded_kernel_summary.txt
+cp gpurun_out/${RUN}_pmc_fetch.txt profiles/${RT}_c4_banded_pmc_fetch_size.txt
+cp gpurun_out/${RUN}_pmc_write.txt profiles/${RT}_c4_banded_pmc_write_size.txt
+for f in gpurun_out/${RUN}_bench_*.json; do b=$(basename $f); cp $f profiles/${b/${RUN}_/${RT}_}; done
+python3 scripts/pmc_to_json.py profiles/${RT}_c4_banded_pmc_fetch_size.txt profiles/${RT}_c4_banded_pmc_write_size.txt c4_500x300k/banded profiles/${RT}_pmc_traffic.json
+python3 scripts/make_profiles_readme.py ${RT}

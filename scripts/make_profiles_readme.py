@@ -1,0 +1,87 @@
+"""Write profiles/README.md from the evidence files of a round (bench lines, rocprofv3 kernel
+statistics, PMC traffic):  python scripts/make_profiles_readme.py r01
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def bench(name):
+    path = os.path.join(P, f"{tag}_bench_{name}.json")
+    if not os.path.exists(path):
+        return None
+    return json.loads(open(path).read().strip().splitlines()[-1])
+
+
+rows = [("default", "c4_500x300k banded (the `bench.py` default)"), ("c4_500x300k_uniform", "c4_500x300k uniform"),
+        ("ladybug50_banded", "ladybug50 banded"), ("ladybug50_uniform", "ladybug50 uniform"),
+        ("venice1800_banded", "venice1800 banded")]
+out = [f"# profiles — round {tag[1:]} evidence (MI355X, one GPU)", "",
+       "Produced by `bash scripts/gpu_evidence.sh <tag>` on the GPU box; this file is generated from the files next to it",
+       "by `scripts/make_profiles_readme.py`.", "",
+       "## Bench lines (`bench.py`, 10 timed Gauss-Newton iterations after 3 warm-up iterations)", "",
+       "| workload | cameras x points x observations | ms/iteration (with / without event records) | observations/s | reduced solve ms (path) | Jacobian / assembly / back-substitution, algorithmic GB/s |",
+       "|---|---|---|---|---|---|"]
+for key, label in rows:
+    d = bench(key)
+    if d is None:
+        continue
+    g = d["roofline"]["groups"]
+    c = d["config"]
+    out.append("| %s | %d x %d x %d | %.3f / %.3f | %.3g | %.3f (%s) | %.0f / %.0f / %.0f |" % (
+        label, c["cameras"], c["points"], c["observations"], d["ms_per_step"], d["ms_per_step_without_events"],
+        d["value"], d["solve"]["ms"], d["solve"].get("path", "blocked Cholesky"), g["jacobian"]["GBps"],
+        g["assembly"]["GBps"], g["back_substitution"]["GBps"]))
+d = bench("default")
+if d is not None:
+    r = d["roofline"]
+    out += ["", "## Default bench line: roofline and CPU baseline", "",
+            f"* dominant HBM-bound stage: {r['kernel']}",
+            "* algorithmic bytes per iteration %.1f MB -> achieved %.0f GB/s = %.1f %% of the %.0f GB/s HBM peak" % (
+                r["groups"][max(r["groups"], key=lambda k: r["groups"][k]["ms"])]["bytes"] / 1e6, r["achieved"],
+                100 * r["frac"], r["peak"]),
+            "* measured HBM traffic of that stage (PMC, below): %s" % (
+                "%.1f MB per iteration" % (r["traffic"] / 1e6) if r.get("traffic") else "not collected for this line"),
+            ]
+    for gname, g in r["groups"].items():
+        out.append("* %s: %.1f us, algorithmic %.1f MB (%.0f GB/s)%s" % (
+            gname, 1e3 * g["ms"], g["bytes"] / 1e6, g["GBps"],
+            ", measured traffic %.1f MB (%.0f GB/s)" % (g["traffic"] / 1e6, g["traffic_GBps"]) if g.get("traffic") else ""))
+    cb = d.get("cpu_baseline")
+    if cb:
+        out += ["* CPU baseline (`kind: %s`, %d BLAS threads): %.3g observations/s — %s" % (
+            cb["kind"], cb["cores"], cb["value"], cb["sample"])]
+    out += ["", "Per-kernel HIP-event times of that line (ms per launch, launches per iteration):", ""]
+    for k, v in d["kernels"].items():
+        out.append("* `%s`: %.4f ms x %.0f" % (k, v["ms_avg"], v["launches_per_step"]))
+summ = os.path.join(P, f"{tag}_c4_banded_kernel_summary.txt")
+if os.path.exists(summ):
+    out += ["", f"## rocprofv3 `--kernel-trace --stats` of the default bench (`{tag}_c4_banded_kernel_stats.csv`)", "",
+            "Average kernel durations agree with the HIP-event times above (the profile covers warm-up, both timed",
+            "passes of `bench.py`: 23 iterations).", "", "```"]
+    out += [line.rstrip()[:150] for line in open(summ)]
+    out += ["```"]
+pmc = os.path.join(P, f"{tag}_pmc_traffic.json")
+if os.path.exists(pmc):
+    doc = json.load(open(pmc))
+    out += ["", "## HBM traffic per launch (rocprofv3 `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, separate passes)", "",
+            "Counters are in KiB. `bytes` = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: on gfx950 FETCH_SIZE tallies a 128-byte",
+            "request of a wide streaming read as 64 bytes, so the read side is doubled; for kernels that read with",
+            "narrower accesses this is an upper bound (the raw counter is kept).", ""]
+    for wl, ks in doc.items():
+        out += [f"### {wl}", "", "| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | corrected MB per launch |", "|---|---|---|---|"]
+        for k, v in ks.items():
+            out.append("| `%s` | %.4g | %.4g | %.2f |" % (k, v["fetch_kib"], v["write_kib"], v["bytes"] / 1e6))
+        out.append("")
+out += ["", "## Files", "",
+        f"* `{tag}_bench_*.json` — the JSON line of each bench run",
+        f"* `{tag}_c4_banded_kernel_stats.csv`, `{tag}_c4_banded_kernel_summary.txt` — rocprofv3 kernel statistics of the default bench",
+        f"* `{tag}_c4_banded_pmc_fetch_size.txt`, `{tag}_c4_banded_pmc_write_size.txt`, `{tag}_pmc_traffic.json` — PMC passes",
+        f"* `{tag}_c4_banded_baseline_kernel_stats.csv` — the first working version of this round (9.4 ms per iteration), for comparison",
+        ""]
+open(os.path.join(P, "README.md"), "w").write("\n".join(out))
+print("wrote profiles/README.md")
