@@ -14,8 +14,7 @@ constexpr int kCamChunk = 1024;    // observations per per-camera work item
 constexpr int kCamThreads = 128;   // threads of a per-camera work item
 constexpr int kPairChunk = 512;   // (obs, obs) entries per camera-pair work item (one wave each)
 constexpr int kPairPad = 64;
-constexpr int kPairPartStride = 56;   // doubles per partial result of a split block: 7x7 block + e_j
-constexpr int kGroupPartStride = 64;  // doubles per partial result of a group-local block (4 column pairs x 16)
+constexpr int kPairPartStride = 56;  // doubles per partial result of a split block: 7x7 block + e_j        // valid records / T rows kept behind the last entry
 
 struct PairEntry {
   int32_t obs_a;  // observation (caller order) of the block's row camera j
@@ -62,17 +61,9 @@ struct sfm_ba_plan {
   int32_t* d_mb_blk = nullptr;
   int32_t* d_mb_part = nullptr;   // first partial
   int32_t* d_mb_cnt = nullptr;    // number of partials
-  // group-local blocks of the fused point-major assembly
-  bool fused = false;             // the plan has enough camera-set reuse for the fused kernel
-  int32_t n_local_blocks = 0;
-  int32_t* d_g_lb_ptr = nullptr;  // [n_groups+1] local blocks of each point range
-  int32_t* d_lb_eptr = nullptr;   // [n_local_blocks+1] pairs of each local block
-  uint16_t* d_gent = nullptr;     // (slot_a | slot_b << 8), slots relative to the range's first slot
-  int32_t* d_blk_pptr = nullptr;  // [n_blocks+1] partials of each block
-  int32_t* d_blk_part = nullptr;  // local block ids, ascending point range
   int64_t device_bytes = 0;
   // workspace section offsets (bytes)
-  int64_t ws_g = 0, ws_T = 0, ws_campart = 0, ws_spart = 0, ws_gpart = 0, ws_total = 0;
+  int64_t ws_g = 0, ws_T = 0, ws_campart = 0, ws_spart = 0, ws_total = 0;
 };
 
 namespace sfmba {
@@ -83,8 +74,7 @@ void set_hip_error(hipError_t err, const char* what);
 // launch stream while profiling is enabled, and costs one branch otherwise
 enum KernelId {
   KID_CAMERA_PREPARE = 0, KID_JACOBIAN, KID_POINT, KID_CAMERA_ITEMS, KID_CAMERA_FINISH, KID_PAIR_BLOCKS,
-  KID_PAIR_FINISH, KID_SOLVE, KID_BACK, KID_UPDATE, KID_COST_ITEMS, KID_COST_FINISH, KID_CALC_W_Y,
-  KID_GROUP_ASSEMBLE, KID_GROUP_FINISH, KID_COUNT
+  KID_PAIR_FINISH, KID_SOLVE, KID_BACK, KID_UPDATE, KID_COST_ITEMS, KID_COST_FINISH, KID_CALC_W_Y, KID_COUNT
 };
 bool profiling_enabled();
 class ProfScope {

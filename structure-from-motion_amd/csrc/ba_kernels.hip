@@ -724,290 +724,6 @@ __global__ __launch_bounds__(64) void k_pair_finish(
 }
 
 // ------------------------------------------------------------------------------------------
-// Fused point-major assembly (plans in which consecutive points are seen by the same cameras).
-// One workgroup owns a range of points with at most kGroupSlots observations and makes one pass
-// over their B, eps and A rows:
-//   1. as k_point: V_i, V_i^-1, eps_b_i per point; (wB)_a, H_a = (wB)_a V^-1 and
-//      g_a = w (eps - B V^-1 eps_b) per observation, all kept in LDS together with the A rows;
-//   2. per camera pair (j, k) that the range covers ("local block") the sum over its observation
-//      pairs of A_a^T (T_ab) A_b with T_ab = H_a (wB)_b^T formed on the fly (minus w_a for an
-//      observation paired with itself, which adds U_j), and for diagonal pairs e_j = sum A_a^T g_a.
-// A wave takes every fourth local block; a step is 16 pairs, lane = 4 * (pair of the step) + h with
-// h = column pair {2h, 2h+1} as in k_pair_blocks.  The 16 partial sums per column pair are combined
-// through a small LDS scratch (four passes of 4 values) instead of a shuffle butterfly, which also
-// leaves one result per lane for a contiguous store.  k_group_finish adds the partial blocks of
-// each camera pair in ascending range order.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_group_assemble(
-    const int32_t* __restrict__ grp_pt, const int32_t* __restrict__ pt_ptr,
-    const int32_t* __restrict__ perm, const int32_t* __restrict__ g_lb_ptr,
-    const int32_t* __restrict__ lb_eptr, const uint16_t* __restrict__ gent,
-    const double* __restrict__ A, const double* __restrict__ B, const double* __restrict__ xt,
-    const double* __restrict__ xpred, const double* __restrict__ wgt, double mu,
-    double* __restrict__ Vinv, double* __restrict__ eps_b, double* __restrict__ gpart) {
-  // sU: first the per-observation contributions to V and eps_b (9 per slot; a point's V^-1 and
-  // V^-1 eps_b then overwrite the contributions of its first slot), later the A rows (14 per slot,
-  // + 2 so that the dummy column of the last slot stays inside the array)
-  __shared__ __attribute__((aligned(16))) double sU[kGroupSlots * 14 + 2];
-  __shared__ __attribute__((aligned(16))) double sBp[kGroupSlots * 6];
-  __shared__ __attribute__((aligned(16))) double sH[kGroupSlots * 6];
-  __shared__ __attribute__((aligned(16))) double sG[kGroupSlots * 2];
-  __shared__ __attribute__((aligned(16))) double sRed[4][68 * 4];
-  __shared__ int sPtr[kGroupSlots + 1];
-  __shared__ int sLp[kGroupSlots];
-  // the range's pair list and block boundaries, staged while phase 1 runs (ranges whose lists do
-  // not fit read them from global memory instead)
-  constexpr int kEntCap = 5120, kLbCap = 255;
-  __shared__ uint16_t sEnt[kEntCap + 32];
-  __shared__ int sEp[kLbCap + 1];
-  const int t = threadIdx.x;
-  const int p0 = grp_pt[blockIdx.x];
-  const int np = grp_pt[blockIdx.x + 1] - p0;
-  const int lb0 = g_lb_ptr[blockIdx.x], lb1 = g_lb_ptr[blockIdx.x + 1];
-  const int eb = lb_eptr[lb0], ne = lb_eptr[lb1] - eb;
-  const bool staged = ne <= kEntCap && lb1 - lb0 <= kLbCap;
-  if (staged) {
-    for (int i = t; i < ne + 32; i += 256) sEnt[i] = gent[eb + i];  // (the global list is padded)
-    for (int i = t; i <= lb1 - lb0; i += 256) sEp[i] = lb_eptr[lb0 + i] - eb;
-  }
-  for (int i = t; i <= np; i += 256) sPtr[i] = pt_ptr[p0 + i];
-  __syncthreads();
-  const int s0 = sPtr[0];
-  const int ns = sPtr[np] - s0;
-  if (t < np)
-    for (int s = sPtr[t]; s < sPtr[t + 1]; ++s) sLp[s - s0] = t;
-
-  double bp[6], we[2], arow[14];
-  if (t < ns) {
-    const int pos = perm[s0 + t];
-    const double* ap = A + 14 * (int64_t)pos;
-#pragma unroll
-    for (int q = 0; q < 7; ++q) {
-      const double2 v2 = ld2(ap + 2 * q);
-      arow[2 * q] = v2.x;
-      arow[2 * q + 1] = v2.y;
-    }
-    const double* b = B + 6 * (int64_t)pos;
-    const double2 b01 = ld2(b), b23 = ld2(b + 2), b45 = ld2(b + 4);
-    const double bb[6] = {b01.x, b01.y, b23.x, b23.y, b45.x, b45.y};
-    const double2 xa = ld2(xt + 2 * (int64_t)pos), xb = ld2(xpred + 2 * (int64_t)pos);
-    const double e0 = xa.x - xb.x, e1 = xa.y - xb.y;
-    double w00 = 1.0, w01 = 0.0, w10 = 0.0, w11 = 1.0;
-    if (wgt) {
-      const double* wp = wgt + 4 * (int64_t)pos;
-      w00 = wp[0]; w01 = wp[1]; w10 = wp[2]; w11 = wp[3];
-    }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      bp[q] = w00 * bb[q] + w01 * bb[3 + q];
-      bp[3 + q] = w10 * bb[q] + w11 * bb[3 + q];
-    }
-    we[0] = w00 * e0 + w01 * e1;
-    we[1] = w10 * e0 + w11 * e1;
-    double* c = sU + 9 * t;
-    c[0] = bb[0] * bp[0] + bb[3] * bp[3];
-    c[1] = bb[0] * bp[1] + bb[3] * bp[4];
-    c[2] = bb[0] * bp[2] + bb[3] * bp[5];
-    c[3] = bb[1] * bp[1] + bb[4] * bp[4];
-    c[4] = bb[1] * bp[2] + bb[4] * bp[5];
-    c[5] = bb[2] * bp[2] + bb[5] * bp[5];
-    c[6] = bb[0] * we[0] + bb[3] * we[1];
-    c[7] = bb[1] * we[0] + bb[4] * we[1];
-    c[8] = bb[2] * we[0] + bb[5] * we[1];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) sBp[6 * t + q] = bp[q];
-  }
-  __syncthreads();
-  if (t < np) {
-    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int first = sPtr[t] - s0;
-    for (int s = first; s < sPtr[t + 1] - s0; ++s) {
-#pragma unroll
-      for (int q = 0; q < 9; ++q) a[q] += sU[9 * s + q];
-    }
-    const double v00 = a[0] + mu, v01 = a[1], v02 = a[2], v11 = a[3] + mu, v12 = a[4], v22 = a[5] + mu;
-    const double c00 = v11 * v22 - v12 * v12;
-    const double c01 = v02 * v12 - v01 * v22;
-    const double c02 = v01 * v12 - v02 * v11;
-    const double c11 = v00 * v22 - v02 * v02;
-    const double c12 = v01 * v02 - v00 * v12;
-    const double c22 = v00 * v11 - v01 * v01;
-    const double det = v00 * c00 + v01 * c01 + v02 * c02;
-    const double id = 1.0 / det;
-    const double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id, i11 = c11 * id, i12 = c12 * id, i22 = c22 * id;
-    // only this thread reads the contributions of this point's slots: overwrite the first one
-    double* vz = sU + 9 * first;
-    vz[0] = i00; vz[1] = i01; vz[2] = i02; vz[3] = i11; vz[4] = i12; vz[5] = i22;
-    vz[6] = i00 * a[6] + i01 * a[7] + i02 * a[8];
-    vz[7] = i01 * a[6] + i11 * a[7] + i12 * a[8];
-    vz[8] = i02 * a[6] + i12 * a[7] + i22 * a[8];
-    double* vo = Vinv + 9 * (int64_t)(p0 + t);
-    vo[0] = i00; vo[1] = i01; vo[2] = i02;
-    vo[3] = i01; vo[4] = i11; vo[5] = i12;
-    vo[6] = i02; vo[7] = i12; vo[8] = i22;
-    double* eo = eps_b + 3 * (int64_t)(p0 + t);
-    eo[0] = a[6]; eo[1] = a[7]; eo[2] = a[8];
-  }
-  __syncthreads();
-  if (t < ns) {
-    const int lp = sLp[t];
-    const double* vz = sU + 9 * (sPtr[lp] - s0);
-    const double i00 = vz[0], i01 = vz[1], i02 = vz[2], i11 = vz[3], i12 = vz[4], i22 = vz[5];
-    const double z0 = vz[6], z1 = vz[7], z2 = vz[8];
-    st2(sG + 2 * t, we[0] - (bp[0] * z0 + bp[1] * z1 + bp[2] * z2),
-        we[1] - (bp[3] * z0 + bp[4] * z1 + bp[5] * z2));
-    double* ho = sH + 6 * t;
-    ho[0] = bp[0] * i00 + bp[1] * i01 + bp[2] * i02;
-    ho[1] = bp[0] * i01 + bp[1] * i11 + bp[2] * i12;
-    ho[2] = bp[0] * i02 + bp[1] * i12 + bp[2] * i22;
-    ho[3] = bp[3] * i00 + bp[4] * i01 + bp[5] * i02;
-    ho[4] = bp[3] * i01 + bp[4] * i11 + bp[5] * i12;
-    ho[5] = bp[3] * i02 + bp[4] * i12 + bp[5] * i22;
-  }
-  __syncthreads();  // every read of the V section of sU is done: the A rows move in
-  if (t < ns) {
-#pragma unroll
-    for (int q = 0; q < 7; ++q) st2(sU + 14 * t + 2 * q, arow[2 * q], arow[2 * q + 1]);
-  }
-  if (t == 0) {
-    sU[kGroupSlots * 14] = 0.0;
-    sU[kGroupSlots * 14 + 1] = 0.0;
-  }
-  __syncthreads();
-
-  const int lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int g = lane >> 2, h = lane & 3;
-  double* red = sRed[wave];
-  auto pair_at = [&](int i) -> unsigned { return staged ? (unsigned)sEnt[i - eb] : (unsigned)gent[i]; };
-  for (int lb = lb0 + wave; lb < lb1; lb += 4) {
-    const int e0 = __builtin_amdgcn_readfirstlane(staged ? eb + sEp[lb - lb0] : lb_eptr[lb]);
-    const int e1 = __builtin_amdgcn_readfirstlane(staged ? eb + sEp[lb - lb0 + 1] : lb_eptr[lb + 1]);
-    // a block is diagonal (j == k) exactly when its pairs couple an observation with itself
-    const unsigned first_ent = pair_at(e0);
-    const bool diag = __builtin_amdgcn_readfirstlane((int)((first_ent & 255u) == (first_ent >> 8)));
-    double acc0[7] = {0, 0, 0, 0, 0, 0, 0}, acc1[7] = {0, 0, 0, 0, 0, 0, 0};
-    double ev0 = 0.0, ev1 = 0.0;
-    unsigned ent = pair_at(e0 + g);  // (the lists are padded: reading past a block's end is harmless)
-    for (int e = e0; e < e1; e += 16) {
-      const unsigned cur = ent;
-      ent = pair_at(e + 16 + g);
-      const bool valid = e + g < e1;
-      const int sa = cur & 255u, sb = cur >> 8;
-      const double* ha = sH + 6 * sa;
-      const double* qb = sBp + 6 * sb;
-      const double2 h01 = ld2(ha), h23 = ld2(ha + 2), h45 = ld2(ha + 4);
-      const double2 q01 = ld2(qb), q23 = ld2(qb + 2), q45 = ld2(qb + 4);
-      double t00 = h01.x * q01.x + h01.y * q01.y + h23.x * q23.x;
-      double t01 = h01.x * q23.y + h01.y * q45.x + h23.x * q45.y;
-      double t10 = h23.y * q01.x + h45.x * q01.y + h45.y * q23.x;
-      double t11 = h23.y * q23.y + h45.x * q45.x + h45.y * q45.y;
-      if (diag) {
-        double w00 = 1.0, w01 = 0.0, w10 = 0.0, w11 = 1.0;
-        if (wgt) {
-          const double* wp = wgt + 4 * (int64_t)perm[s0 + sa];
-          w00 = wp[0]; w01 = wp[1]; w10 = wp[2]; w11 = wp[3];
-        }
-        t00 -= w00; t01 -= w01; t10 -= w10; t11 -= w11;
-      }
-      if (!valid) t00 = t01 = t10 = t11 = 0.0;
-      const double* ra = sU + 14 * sa;
-      const double* rb = sU + 14 * sb;
-      const double2 b0 = ld2(rb + 2 * h);  // A_b[0][2h], A_b[0][2h+1]
-      const double b10 = rb[7 + 2 * h], b11 = rb[8 + 2 * h];
-      const double p00 = t00 * b0.x + t01 * b10, p10 = t10 * b0.x + t11 * b10;
-      const double p01 = t00 * b0.y + t01 * b11, p11 = t10 * b0.y + t11 * b11;
-      if (diag) {
-        double2 gv = ld2(sG + 2 * sa);
-        if (!valid) gv = make_double2(0.0, 0.0);
-        ev0 = fma(b10, gv.y, fma(b0.x, gv.x, ev0));
-        ev1 = fma(b11, gv.y, fma(b0.y, gv.x, ev1));
-      }
-      double a[14];
-#pragma unroll
-      for (int q2 = 0; q2 < 7; ++q2) {
-        const double2 v2 = ld2(ra + 2 * q2);
-        a[2 * q2] = v2.x;
-        a[2 * q2 + 1] = v2.y;
-      }
-#pragma unroll
-      for (int r = 0; r < 7; ++r) {
-        acc0[r] = fma(a[7 + r], p10, fma(a[r], p00, acc0[r]));
-        acc1[r] = fma(a[7 + r], p11, fma(a[r], p01, acc1[r]));
-      }
-    }
-    // 16 values per lane: v = 0..6 column 2h, 7..13 column 2h+1, 14/15 e of the two columns.  Sum
-    // over the 16 pair lanes of each h in a fixed order; output (h, v) ends up in lane 16 h + v.
-    const double vals[16] = {acc0[0], acc0[1], acc0[2], acc0[3], acc0[4], acc0[5], acc0[6], acc1[0],
-                             acc1[1], acc1[2], acc1[3], acc1[4], acc1[5], acc1[6], ev0,     ev1};
-    double out = 0.0;
-    const int ho = lane >> 4, vo = lane & 15;
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      // scratch row q (stride 68 doubles: conflict-free for the stores and for the reads below)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) red[q * 68 + lane] = vals[4 * pass + q];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      // lane 16 h' + v' with v' in this pass's quarter sums the 16 pair lanes 4 g'' + h'
-      if ((vo >> 2) == pass) {
-        double sacc = 0.0;
-#pragma unroll
-        for (int gg = 0; gg < 16; ++gg) sacc += red[(vo & 3) * 68 + 4 * gg + ho];
-        out = sacc;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    }
-    gpart[(int64_t)lb * kGroupPartStride + lane] = out;
-  }
-}
-
-// S block (and mirror), e_j: sum of the block's partials in ascending range order.  One workgroup
-// per block; its four waves each take every fourth partial, then the four sums are added in order.
-__global__ __launch_bounds__(256) void k_group_finish(
-    const int32_t* __restrict__ blk_pptr, const int32_t* __restrict__ blk_part,
-    const int32_t* __restrict__ blk_j, const int32_t* __restrict__ blk_k,
-    const double* __restrict__ gpart, double mu_u, int m, double* __restrict__ S,
-    double* __restrict__ e_out) {
-  __shared__ double part[4][64];
-  const int t = threadIdx.x;
-  const int lane = t & 63, q = t >> 6;
-  const int b = blockIdx.x;
-  const int i0 = blk_pptr[b], i1 = blk_pptr[b + 1];
-  double a0 = 0.0, a1 = 0.0;
-  int i = i0 + q;
-  for (; i + 4 < i1; i += 8) {
-    const double v0 = gpart[(int64_t)blk_part[i] * kGroupPartStride + lane];
-    const double v1 = gpart[(int64_t)blk_part[i + 4] * kGroupPartStride + lane];
-    a0 += v0;
-    a1 += v1;
-  }
-  if (i < i1) a0 += gpart[(int64_t)blk_part[i] * kGroupPartStride + lane];
-  part[q][lane] = a0 + a1;
-  __syncthreads();
-  if (t >= 64) return;
-  const double a = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
-  const int h = t >> 4, v = t & 15;
-  const int j = blk_j[b], k = blk_k[b];
-  const int64_t ld = 7 * (int64_t)m;
-  if (v >= 14) {
-    const int c = 2 * h + (v - 14);
-    if (j == k && c < 7) {
-      S[ld * ld + 7 * j + c] = a;
-      if (e_out) e_out[7 * j + c] = a;
-    }
-    return;
-  }
-  const int r = v % 7, c = 2 * h + v / 7;
-  if (c >= 7) return;
-  if (j == k) {
-    S[(7 * (int64_t)j + r) * ld + 7 * k + c] = (r == c ? mu_u : 0.0) - a;
-  } else {
-    S[(7 * (int64_t)j + r) * ld + 7 * k + c] = -a;
-    S[(7 * (int64_t)k + c) * ld + 7 * j + r] = -a;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // W = A^T w B and Y = W V^-1[point] per observation (only for callers that want them)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_calc_W_Y(int64_t N, const double* __restrict__ A,
@@ -1270,22 +986,6 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
   // Callers that want none of the per-camera by-products (U, eps_a, the all-reduce records) get
   // them folded into the camera-pair kernel: no separate pass over A.
   const int fold_u = (S && !U && !eps_a && !cam_red) ? 1 : 0;
-  if (fold_u && p->fused && p->n_groups > 0) {
-    double* gpart = reinterpret_cast<double*>(base + p->ws_gpart);
-    {
-      ProfScope ps(KID_GROUP_ASSEMBLE, st);
-      hipLaunchKernelGGL(k_group_assemble, dim3(p->n_groups), dim3(256), 0, st, p->d_grp_pt, p->d_pt_ptr, p->d_perm,
-                         p->d_g_lb_ptr, p->d_lb_eptr, p->d_gent, A, B, xt, xp, w, mu, Vinv, eps_b, gpart);
-    }
-    int rc = check_launch("k_group_assemble");
-    if (rc) return rc;
-    {
-      ProfScope ps(KID_GROUP_FINISH, st);
-      hipLaunchKernelGGL(k_group_finish, dim3(p->n_blocks), dim3(256), 0, st, p->d_blk_pptr, p->d_blk_part,
-                         p->d_blk_j, p->d_blk_k, gpart, mu_u, p->m, S, e);
-    }
-    return check_launch("k_group_finish");
-  }
   if (p->n_groups > 0) {
     {
     ProfScope ps(KID_POINT, st);

@@ -41,7 +41,7 @@ extern "C" void sfm_ba_plan_destroy(sfm_ba_plan* p) {
   void* ptrs[] = {p->d_pt_ptr,   p->d_perm,     p->d_slot_cam, p->d_tp_ptr,  p->d_grp_pt,  p->d_cam_obs, p->d_pair_entry,
                   p->d_item_cam, p->d_item_beg, p->d_item_end, p->d_cam_item_ptr, p->d_blk_j, p->d_blk_k,
                   p->d_entries,  p->d_pit_blk,  p->d_pit_beg,  p->d_pit_end, p->d_pit_part, p->d_mb_blk,
-                  p->d_mb_part,  p->d_mb_cnt,   p->d_g_lb_ptr, p->d_lb_eptr, p->d_gent, p->d_blk_pptr, p->d_blk_part};
+                  p->d_mb_part,  p->d_mb_cnt};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   delete p;
@@ -158,7 +158,6 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   std::vector<PairEntry> entries;
   std::vector<int32_t> pair_entry((size_t)pairs);
   int32_t max_cam_dist = 0;
-  std::vector<int32_t> blk_index((size_t)m * m, -1);  // (j, k), j <= k -> block id
   {
     std::vector<int64_t> cnt((size_t)m * m, 0);
     for (int32_t i = 0; i < n; ++i)
@@ -172,7 +171,6 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
           cnt[(size_t)j * m + k] = -1;
           continue;
         }
-        blk_index[(size_t)j * m + k] = (int32_t)blk_j.size();
         blk_j.push_back(j);
         blk_k.push_back(k);
         max_cam_dist = std::max(max_cam_dist, k - j);
@@ -199,60 +197,6 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   p->n_blocks = (int32_t)blk_j.size();
   p->max_cam_dist = max_cam_dist;
   p->n_entries = (int64_t)entries.size();
-  // ---- group-local camera-pair blocks (fused point-major assembly) ----
-  // For every workgroup range of points: the distinct camera pairs its points cover ("local blocks",
-  // ordered by block id) and per local block the (slot, slot) pairs that feed it, slots counted from
-  // the range's first slot (< kGroupSlots, so 8 bits each).  Every local block yields one partial
-  // 7x7 result; a block's partials are summed in ascending range order.
-  std::vector<int32_t> g_lb_ptr(grp_pt.size(), 0), lb_blk, lb_eptr, blk_pptr(blk_j.size() + 1, 0), blk_part;
-  std::vector<uint16_t> gent;
-  gent.reserve((size_t)pairs);
-  {
-    std::vector<int32_t> key, start;  // per range: block id of each pair, bucket starts
-    std::vector<uint16_t> val;
-    std::vector<int32_t> ids;
-    for (size_t g = 0; g + 1 < grp_pt.size(); ++g) {
-      const int32_t s0 = pt_ptr[grp_pt[g]];
-      key.clear();
-      val.clear();
-      for (int32_t i = grp_pt[g]; i < grp_pt[g + 1]; ++i)
-        for (int32_t a = pt_ptr[i]; a < pt_ptr[i + 1]; ++a)
-          for (int32_t b = a; b < pt_ptr[i + 1]; ++b) {
-            key.push_back(blk_index[(size_t)slot_cam[a] * m + slot_cam[b]]);
-            val.push_back((uint16_t)((a - s0) | ((b - s0) << 8)));
-          }
-      ids.assign(key.begin(), key.end());
-      std::sort(ids.begin(), ids.end());
-      ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
-      // stable bucket sort of the range's pairs by block id (pairs are generated in point order)
-      start.assign(ids.size() + 1, 0);
-      for (int32_t kb : key) ++start[(std::lower_bound(ids.begin(), ids.end(), kb) - ids.begin()) + 1];
-      for (size_t q = 0; q < ids.size(); ++q) start[q + 1] += start[q];
-      const size_t base = gent.size();
-      gent.resize(base + key.size());
-      for (size_t q = 0; q < ids.size(); ++q) {
-        lb_blk.push_back(ids[q]);
-        lb_eptr.push_back((int32_t)(base + start[q]));
-        ++blk_pptr[ids[q] + 1];
-      }
-      for (size_t e = 0; e < key.size(); ++e) {
-        const size_t q = std::lower_bound(ids.begin(), ids.end(), key[e]) - ids.begin();
-        gent[base + start[q]++] = val[e];
-      }
-      g_lb_ptr[g + 1] = (int32_t)lb_blk.size();
-    }
-    lb_eptr.push_back((int32_t)gent.size());
-    for (size_t b = 0; b < blk_j.size(); ++b) blk_pptr[b + 1] += blk_pptr[b];
-    blk_part.resize(lb_blk.size());
-    std::vector<int32_t> fill(blk_pptr.begin(), blk_pptr.end() - 1);
-    for (size_t lb = 0; lb < lb_blk.size(); ++lb) blk_part[fill[lb_blk[lb]]++] = (int32_t)lb;
-  }
-  p->n_local_blocks = (int32_t)lb_blk.size();
-  // worth it when a local block collects several pairs (consecutive points seen by the same
-  // cameras); with no reuse every pair would become a partial block of its own
-  p->fused = lb_blk.size() * 3 <= gent.size();
-  gent.resize(gent.size() + 64, 0);  // the kernel prefetches one 16-pair step past a block's end
-
   // the camera-pair kernel fetches whole 32-entry steps: keep one step of valid records (and, in
   // the workspace, of T rows) behind the last entry
   entries.resize(entries.size() + kPairPad, PairEntry{0, 0});
@@ -305,11 +249,6 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   up(mb_blk, &p->d_mb_blk);
   up(mb_part, &p->d_mb_part);
   up(mb_cnt, &p->d_mb_cnt);
-  up(g_lb_ptr, &p->d_g_lb_ptr);
-  up(lb_eptr, &p->d_lb_eptr);
-  up(gent, &p->d_gent);
-  up(blk_pptr, &p->d_blk_pptr);
-  up(blk_part, &p->d_blk_part);
   if (rc != SFM_BA_OK) {
     sfm_ba_plan_destroy(p);
     return rc;
@@ -326,8 +265,6 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   off = align256(off + (int64_t)std::max(p->n_items, 1) * SFM_BA_CAM_RED * (int64_t)sizeof(double));
   p->ws_spart = off;
   off = align256(off + (int64_t)std::max(n_parts, 1) * kPairPartStride * (int64_t)sizeof(double));
-  p->ws_gpart = off;
-  if (p->fused) off = align256(off + (int64_t)std::max(p->n_local_blocks, 1) * kGroupPartStride * (int64_t)sizeof(double));
   p->ws_total = off;
   *out = p;
   return SFM_BA_OK;
