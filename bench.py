@@ -238,7 +238,7 @@ def main():
                 "cameras": m, "points": n_total, "observations": N_total, "visibility": args.visibility,
                 "nonzero_S_blocks": s_blocks,
                 "parallelism": "1 gpu" if world == 1 else f"point-id sharding x{world}, all-reduce of "
-                               f"{packed_system_elements(m) * 8 / 1e6:.1f} MB per iteration",
+                               f"{packed_system_elements(m, prob.half_bandwidth) * 8 / 1e6:.1f} MB per iteration",
             },
             "final_cost": final_cost,
             "roofline": roofline,

@@ -175,6 +175,21 @@ int sfm_ba_solve_reduced(double* d_S, int32_t n7, double* d_delta_a, void* d_cho
 int sfm_ba_solve_reduced_banded(double* d_S, int32_t n7, int32_t half_bandwidth, double* d_delta_a,
                                 void* d_chol_ws, int32_t* d_info, void* stream);
 
+/* Packed form of a narrow-band system (half bandwidth <= 64), for sharded runs: S is block
+ * tridiagonal in 64 x 64 blocks, and [diagonal blocks | couplings | right-hand side] is all of it -
+ * 8 (2 * 64 * 7m + 7m) bytes rounded up to whole blocks instead of the 8 (7m + 1) 7m of the dense
+ * buffer (3.6 MB instead of 98 MB at m = 500).  Packing is a copy, so ranks pack their local sums,
+ * all-reduce the packed buffers and solve from the packed form; `mu_diag` is the damping of U
+ * (src/sparse_ba.py:194-197), added once after the reduction.  No counterpart in the reference,
+ * whose calc_S (src/sparse_ba.py:237-258) always fills the dense matrix.
+ *   d_packed  : sfm_ba_band_packed_elements(n7) doubles; destroyed by the solve
+ *   d_chol_ws : sfm_ba_cholesky_workspace_bytes(n7) bytes
+ * Entries of d_S outside the band are not read. */
+int64_t sfm_ba_band_packed_elements(int32_t n7);
+int sfm_ba_band_pack(const double* d_S, int32_t n7, double* d_packed, void* stream);
+int sfm_ba_solve_band_packed(double* d_packed, int32_t n7, double mu_diag, double* d_delta_a,
+                             void* d_chol_ws, int32_t* d_info, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Back-substitution.  Work of `calc_delta_b` (src/sparse_ba.py:279-290):
  * delta_b_i = V_inv_i (eps_b_i - sum_j W_ij^T delta_a_j).

@@ -73,6 +73,20 @@ int sfm_ba_solve_reduced_banded(double* d_S, int32_t n7, int32_t half_bandwidth,
                               static_cast<hipStream_t>(stream));
 }
 
+int64_t sfm_ba_band_packed_elements(int32_t n7) { return n7 > 0 ? band_packed_elements(n7) : 0; }
+
+int sfm_ba_band_pack(const double* d_S, int32_t n7, double* d_packed, void* stream) {
+  if (!d_S || !d_packed || n7 <= 0) return SFM_BA_EINVAL;
+  return launch_band_pack(d_S, n7, d_packed, static_cast<hipStream_t>(stream));
+}
+
+int sfm_ba_solve_band_packed(double* d_packed, int32_t n7, double mu_diag, double* d_delta_a, void* d_chol_ws,
+                             int32_t* d_info, void* stream) {
+  if (!d_packed || !d_delta_a || !d_chol_ws || !d_info || n7 <= 0) return SFM_BA_EINVAL;
+  return launch_solve_band_packed(d_packed, n7, mu_diag, d_delta_a, d_chol_ws, d_info,
+                                  static_cast<hipStream_t>(stream));
+}
+
 int sfm_ba_back_substitute(const sfm_ba_plan* plan, const double* d_A, const double* d_B, const double* d_weights,
                            const double* d_V_inv, const double* d_eps_b, const double* d_delta_a,
                            double* d_delta_b, double* d_X_update, double x_step, void* stream) {

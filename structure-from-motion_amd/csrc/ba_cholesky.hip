@@ -1096,14 +1096,47 @@ __global__ __launch_bounds__(256) void k_bcr_back(int n, int np, int s, int j0, 
   }
 }
 
-static int launch_solve_bcr(const double* S, int n, double* da, void* ws, int32_t* info, hipStream_t st) {
+// packed block-tridiagonal form: [np][64*64] diagonal blocks, [np][64*64] couplings, [np*64] right-hand side
+int64_t band_packed_elements(int n) {
+  const int64_t np = (n + NB - 1) / NB;
+  return 2 * np * NB * NB + np * NB;
+}
+
+int launch_band_pack(const double* S, int n, double* packed, hipStream_t st) {
   const int np = (n + NB - 1) / NB;
-  double* Dk = static_cast<double*>(ws);
+  double* Dk = packed;
   double* Bk = Dk + (int64_t)np * NB * NB;
-  double* Pu = Bk + (int64_t)np * NB * NB;
-  double* Pd = Pu + (int64_t)np * NB * NB;
-  double* ek = Pd + (int64_t)np * NB * NB;
+  double* ek = Bk + (int64_t)np * NB * NB;
   hipLaunchKernelGGL(k_bcr_extract, dim3(np), dim3(256), 0, st, S, n, np, Dk, Bk, ek);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_hip_error(err, "k_bcr_extract launch");
+    return SFM_BA_EHIP;
+  }
+  return SFM_BA_OK;
+}
+
+// damping added after a sharded run's all-reduce: the diagonal of S lives in the diagonal blocks
+__global__ void k_bcr_add_diagonal(double* __restrict__ Dk, int n, double mu) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) Dk[(int64_t)(i / NB) * NB * NB + (i % NB) * (NB + 1)] += mu;
+}
+
+// cyclic reduction on the packed form (destroyed); P_u, P_d go to `ws` (2 np 64*64 doubles)
+int launch_solve_band_packed(double* packed, int n, double mu_diag, double* da, void* ws, int32_t* info,
+                             hipStream_t st) {
+  const int np = (n + NB - 1) / NB;
+  double* Dk = packed;
+  double* Bk = Dk + (int64_t)np * NB * NB;
+  double* ek = Bk + (int64_t)np * NB * NB;
+  double* Pu = static_cast<double*>(ws);
+  double* Pd = Pu + (int64_t)np * NB * NB;
+  hipError_t err = hipMemsetAsync(info, 0, sizeof(int32_t), st);
+  if (err != hipSuccess) {
+    set_hip_error(err, "hipMemsetAsync(info)");
+    return SFM_BA_EHIP;
+  }
+  if (mu_diag != 0.0) hipLaunchKernelGGL(k_bcr_add_diagonal, dim3((n + 255) / 256), dim3(256), 0, st, Dk, n, mu_diag);
   int s = 1;
   for (; s < np; s *= 2) {
     const int m = (np + s - 1) / s;  // active blocks 0, s, 2s, ...
@@ -1117,7 +1150,7 @@ static int launch_solve_bcr(const double* S, int n, double* da, void* ws, int32_
     const int m = (np + s - 1) / s;
     hipLaunchKernelGGL(k_bcr_back, dim3(m / 2), dim3(256), 0, st, n, np, s, 1, Dk, Pu, Pd, ek, da);
   }
-  const hipError_t err = hipGetLastError();
+  err = hipGetLastError();
   if (err != hipSuccess) {
     set_hip_error(err, "cyclic reduction launches");
     return SFM_BA_EHIP;
@@ -1143,7 +1176,13 @@ int launch_solve_reduced(double* S, int n, int half_bandwidth, double* da, void*
     return SFM_BA_EHIP;
   }
   if (half_bandwidth >= 0 && half_bandwidth <= NB) {
-    if (np >= 4) return launch_solve_bcr(S, n, da, ws, info, st);
+    if (np >= 4) {
+      // packed form in the first part of the workspace, P_u / P_d behind it
+      double* packed = static_cast<double*>(ws);
+      const int rc = launch_band_pack(S, n, packed, st);
+      if (rc != SFM_BA_OK) return rc;
+      return launch_solve_band_packed(packed, n, 0.0, da, packed + band_packed_elements(n), info, st);
+    }
     double* p_ws = reinterpret_cast<double*>(zflags);
     hipLaunchKernelGGL(k_chol_band, dim3(1), dim3(256), 0, st, S, n, invL, p_ws, y, da, info);
     err = hipGetLastError();

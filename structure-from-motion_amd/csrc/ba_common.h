@@ -124,4 +124,9 @@ int64_t cholesky_workspace_bytes(int n7);
 // half_bandwidth < 0: dense; otherwise S[r][c] = 0 wherever |r - c| > half_bandwidth
 int launch_solve_reduced(double* S, int n7, int half_bandwidth, double* da, void* ws, int32_t* info, hipStream_t st);
 
+int64_t band_packed_elements(int n7);
+int launch_band_pack(const double* S, int n7, double* packed, hipStream_t st);
+int launch_solve_band_packed(double* packed, int n7, double mu_diag, double* da, void* ws, int32_t* info,
+                             hipStream_t st);
+
 }  // namespace sfmba

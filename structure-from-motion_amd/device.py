@@ -171,6 +171,11 @@ class DeviceProblem:
         self.workspace = torch.empty((max(self.plan.workspace_bytes, 256) // 8,), dtype=F64, device=d)
         self.chol_ws = torch.empty((int(self.lib.sfm_ba_cholesky_workspace_bytes(n7)) // 8 + 8,), dtype=F64, device=d)
         self.info = torch.zeros((1,), dtype=I32, device=d)
+        # sharded run with a narrow band: what the ranks all-reduce (see assemble)
+        self.band_sharded = self.sharded and self.half_bandwidth <= 64
+        self._packed_mu = None
+        if self.band_sharded:
+            self.packed = torch.empty((int(self.lib.sfm_ba_band_packed_elements(n7)),), dtype=F64, device=d)
         self.cost_buf = torch.zeros((1,), dtype=F64, device=d)
 
     # -- single stages ---------------------------------------------------------------------
@@ -190,13 +195,20 @@ class DeviceProblem:
         _lib.check(self.lib.sfm_ba_jacobian(p(self.cam_blk), p(self.P), p(self.X), p(self.cam_idx), p(self.pt_idx),
                                             self.N, None, None, p(self.x_pred), _stream()))
 
-    def assemble(self, mu, weights=None, x_true=None, x_pred=None, A=None, B=None, by_products=True):
+    def assemble(self, mu, weights=None, x_true=None, x_pred=None, A=None, B=None, by_products=True,
+                 reduce_packed=False):
         """``by_products=False`` skips U and eps_a (the solve needs only S and e): the library then
         folds the per-camera sums into the camera-pair kernel and makes one pass less over A."""
         p = _lib.ptr
         mu_u = 0.0 if self.sharded else mu
         n7 = self.n7
-        if self.plan.n_blocks < self.m * (self.m + 1) // 2 and (self.sharded or self.half_bandwidth > 64):
+        # ``reduce_packed`` (sharded run, narrow band): the ranks exchange the packed block-tridiagonal
+        # form instead of the dense buffer; S then keeps this rank's sums only and solve() works
+        # from ``self.packed``.
+        reduce_packed = bool(reduce_packed) and self.band_sharded
+        self._packed_mu = float(mu) if reduce_packed else None
+        if (self.plan.n_blocks < self.m * (self.m + 1) // 2 and not reduce_packed
+                and (self.sharded or self.half_bandwidth > 64)):
             # camera pairs without a shared point are not written by the kernels; the previous
             # factorisation left fill-in there (the narrow-band solve only reads S), and the
             # all-reduce of a sharded run left the other ranks' blocks there
@@ -208,7 +220,13 @@ class DeviceProblem:
             p(weights), float(mu), float(mu_u), p(self.S), p(self.e), p(self.U) if by_products else None,
             p(self.eps_a) if by_products else None,
             p(self.V_inv), p(self.eps_b), None, p(self.workspace), _stream()))
-        if self.sharded:
+        if reduce_packed:
+            import torch.distributed as dist
+
+            # blocks and right-hand-side entries this rank never writes stay zero from allocation
+            _lib.check(self.lib.sfm_ba_band_pack(p(self.S), n7, p(self.packed), _stream()))
+            dist.all_reduce(self.packed, group=self.group)
+        elif self.sharded:
             import torch.distributed as dist
 
             dist.all_reduce(self.sys[: (n7 + 1) * n7], group=self.group)
@@ -217,6 +235,10 @@ class DeviceProblem:
 
     def solve(self):
         p = _lib.ptr
+        if self._packed_mu is not None:
+            _lib.check(self.lib.sfm_ba_solve_band_packed(p(self.packed), self.n7, self._packed_mu, p(self.delta_a),
+                                                         p(self.chol_ws), p(self.info), _stream()))
+            return
         _lib.check(self.lib.sfm_ba_solve_reduced_banded(p(self.S), self.n7, self.half_bandwidth, p(self.delta_a),
                                                         p(self.chol_ws), p(self.info), _stream()))
 
@@ -254,7 +276,7 @@ class DeviceProblem:
         mu = self.MU if mu is None else mu
         self.camera_prepare()
         self.jacobian()
-        self.assemble(mu, by_products=False)
+        self.assemble(mu, by_products=False, reduce_packed=True)
         self.solve()
         self.back_substitute(update_points=True)
         self.update_cameras()

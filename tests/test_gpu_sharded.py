@@ -12,7 +12,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+# (cameras, points, views): 84 unknowns = 2 blocks of 64; 420 unknowns = 7 blocks (three rounds of the
+# cyclic reduction).  Both are banded, so the ranks exchange the packed block-tridiagonal system.
+PROBLEMS = {"small": (12, 3000, 4), "chain7": (60, 6000, 5)}
+
+
+def _worker(rank, world, port, q, which="small"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -27,10 +32,12 @@ def _worker(rank, world, port, q):
         from sfm_amd.device import DeviceProblem
         from sfm_amd.dist import local_problem
 
-        full = synthetic.make_problem(12, 3000, k=4, visibility="banded", seed=6)
+        m, n, k = PROBLEMS[which]
+        full = synthetic.make_problem(m, n, k=k, visibility="banded", seed=6)
         loc, (p0, p1) = local_problem(full, rank, world)
         prob = DeviceProblem(loc.K, loc.R, loc.T, loc.X, loc.cam_idx, loc.pt_idx, loc.x_true, n_cams=full.m,
                              group=dist.group.WORLD, check=False)
+        assert prob.band_sharded
         c0 = prob.cost()
         costs = prob.run(max_iter=3, threshold=0.0)
         R, T, C, P = prob.cameras()
@@ -39,7 +46,8 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_process():
+@pytest.mark.parametrize("which", ["small", "chain7"])
+def test_two_ranks_match_single_process(which):
     import torch.multiprocessing as mp
 
     import sfm_amd  # noqa: F401
@@ -50,7 +58,7 @@ def test_two_ranks_match_single_process():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29700 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, which)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in range(world)]
@@ -59,7 +67,8 @@ def test_two_ranks_match_single_process():
         assert p.exitcode == 0
     results.sort(key=lambda r: r[0])
 
-    full = synthetic.make_problem(12, 3000, k=4, visibility="banded", seed=6)
+    m, n, k = PROBLEMS[which]
+    full = synthetic.make_problem(m, n, k=k, visibility="banded", seed=6)
     one = DeviceProblem(full.K, full.R, full.T, full.X, full.cam_idx, full.pt_idx, full.x_true)
     c0 = one.cost()
     costs = one.run(max_iter=3, threshold=0.0)
@@ -89,12 +98,16 @@ def test_forced_sharded_flow_single_rank():
     os.environ["MASTER_PORT"] = str(29900 + (os.getpid() % 90))
     dist.init_process_group("gloo", rank=0, world_size=1)
     try:
-        p = synthetic.make_problem(10, 2000, k=4, seed=2)
-        a = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true)
-        b = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true, group=dist.group.WORLD, sharded=True)
-        ca = a.run(max_iter=3, threshold=0.0)
-        cb = b.run(max_iter=3, threshold=0.0)
-        assert np.max(np.abs(np.asarray(ca) - np.asarray(cb)) / np.asarray(ca)) < 1e-10
-        assert np.max(np.abs(a.points() - b.points())) < 1e-10
+        # uniform visibility: dense system, all-reduce of the whole buffer; banded: packed exchange
+        for vis, packed in (("uniform", False), ("banded", True)):
+            p = synthetic.make_problem(10 if vis == "uniform" else 40, 2000, k=4, visibility=vis, seed=2)
+            a = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true)
+            b = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true, group=dist.group.WORLD,
+                              sharded=True)
+            assert b.band_sharded == packed
+            ca = a.run(max_iter=3, threshold=0.0)
+            cb = b.run(max_iter=3, threshold=0.0)
+            assert np.max(np.abs(np.asarray(ca) - np.asarray(cb)) / np.asarray(ca)) < 1e-10
+            assert np.max(np.abs(a.points() - b.points())) < 1e-10
     finally:
         dist.destroy_process_group()
