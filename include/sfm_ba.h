@@ -227,6 +227,16 @@ int sfm_ba_cost_partial(const sfm_ba_plan* plan, const double* d_P, const double
 int sfm_ba_cost_finish(const double* d_cam_ssq, int32_t m, double* d_cost, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Two-view linear triangulation: the step that produces the points bundle adjustment starts from.
+ * Work of `triangulate_pts` (src/triangulation.py:10-32): per correspondence the null direction of
+ * [ [x1]_x P1 ; [x2]_x P2 ] (src/utils.py:4-5 for [v]_x), divided by its last entry, as float32.
+ *   d_x1, d_x2 [n,3] homogeneous pixel coordinates (fp64); d_P1, d_P2 [12] row-major 3x4
+ *   d_Xh [n,4] float32 out (last column 1)
+ * ---------------------------------------------------------------------------------------- */
+int sfm_ba_triangulate(const double* d_x1, const double* d_x2, const double* d_P1, const double* d_P2,
+                       int64_t n, float* d_Xh, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel timing (no counterpart in the reference, which has no profiler).  While enabled,
  * every kernel launch made by the entry points above is bracketed by two HIP events recorded on
  * the launch stream; sfm_ba_profile_read waits for them, adds the elapsed milliseconds and launch

@@ -77,10 +77,21 @@ if os.path.exists(pmc):
         for k, v in ks.items():
             out.append("| `%s` | %.4g | %.4g | %.2f |" % (k, v["fetch_kib"], v["write_kib"], v["bytes"] / 1e6))
         out.append("")
+tri = os.path.join(P, f"{tag}_triangulate.json")
+if os.path.exists(tri):
+    t = json.loads(open(tri).read().strip().splitlines()[-1])
+    out += ["", "## Two-view triangulation (`scripts/bench_triangulate.py`, inputs resident in HBM)", "",
+            "* %d correspondences: %.3g correspondences/s, kernel %.0f us per launch (HIP events)" % (t["n"], t["value"], t["kernel_us"]),
+            "* algorithmic 64 B per correspondence -> %.0f GB/s = %.1f %% of the HBM peak: the kernel is bound by the fp64"
+            " arithmetic of the Jacobi sweeps (about five sweeps of six column rotations per correspondence), not by memory" % (
+                t["roofline"]["achieved"], 100 * t["roofline"]["frac"]),
+            "* CPU baseline (`kind: port`): %.3g correspondences/s — %s" % (t["cpu_baseline"]["value"], t["cpu_baseline"]["sample"]),
+            "* largest difference from the oracle after rounding to float32: %.1e of the largest coordinate" % t["max_rel_diff_vs_oracle"]]
 out += ["", "## Files", "",
         f"* `{tag}_bench_*.json` — the JSON line of each bench run",
         f"* `{tag}_c4_banded_kernel_stats.csv`, `{tag}_c4_banded_kernel_summary.txt` — rocprofv3 kernel statistics of the default bench",
         f"* `{tag}_c4_banded_pmc_fetch_size.txt`, `{tag}_c4_banded_pmc_write_size.txt`, `{tag}_pmc_traffic.json` — PMC passes",
+        f"* `{tag}_triangulate.json` — triangulation benchmark line",
         f"* `{tag}_c4_banded_baseline_kernel_stats.csv` — the first working version of this round (9.4 ms per iteration), for comparison",
         ""]
 open(os.path.join(P, "README.md"), "w").write("\n".join(out))

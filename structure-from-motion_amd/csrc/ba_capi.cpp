@@ -73,6 +73,12 @@ int sfm_ba_solve_reduced_banded(double* d_S, int32_t n7, int32_t half_bandwidth,
                               static_cast<hipStream_t>(stream));
 }
 
+int sfm_ba_triangulate(const double* d_x1, const double* d_x2, const double* d_P1, const double* d_P2, int64_t n,
+                       float* d_Xh, void* stream) {
+  if (n < 0 || (n > 0 && (!d_x1 || !d_x2 || !d_P1 || !d_P2 || !d_Xh))) return SFM_BA_EINVAL;
+  return launch_triangulate(d_x1, d_x2, d_P1, d_P2, n, d_Xh, static_cast<hipStream_t>(stream));
+}
+
 int64_t sfm_ba_band_packed_elements(int32_t n7) { return n7 > 0 ? band_packed_elements(n7) : 0; }
 
 int sfm_ba_band_pack(const double* d_S, int32_t n7, double* d_packed, void* stream) {

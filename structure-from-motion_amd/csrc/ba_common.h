@@ -74,7 +74,7 @@ void set_hip_error(hipError_t err, const char* what);
 // launch stream while profiling is enabled, and costs one branch otherwise
 enum KernelId {
   KID_CAMERA_PREPARE = 0, KID_JACOBIAN, KID_POINT, KID_CAMERA_ITEMS, KID_CAMERA_FINISH, KID_PAIR_BLOCKS,
-  KID_PAIR_FINISH, KID_SOLVE, KID_BACK, KID_UPDATE, KID_COST_ITEMS, KID_COST_FINISH, KID_CALC_W_Y, KID_COUNT
+  KID_PAIR_FINISH, KID_SOLVE, KID_BACK, KID_UPDATE, KID_COST_ITEMS, KID_COST_FINISH, KID_CALC_W_Y, KID_TRIANGULATE, KID_COUNT
 };
 bool profiling_enabled();
 class ProfScope {
@@ -128,5 +128,8 @@ int64_t band_packed_elements(int n7);
 int launch_band_pack(const double* S, int n7, double* packed, hipStream_t st);
 int launch_solve_band_packed(double* packed, int n7, double mu_diag, double* da, void* ws, int32_t* info,
                              hipStream_t st);
+
+int launch_triangulate(const double* x1, const double* x2, const double* P1, const double* P2, int64_t n, float* Xh,
+                       hipStream_t st);
 
 }  // namespace sfmba
