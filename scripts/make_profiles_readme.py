@@ -80,7 +80,7 @@ if os.path.exists(pmc):
 tri = os.path.join(P, f"{tag}_triangulate.json")
 if os.path.exists(tri):
     t = json.loads(open(tri).read().strip().splitlines()[-1])
-    out += ["", "## Two-view triangulation (`scripts/bench_triangulate.py`, inputs resident in HBM)", "",
+    out += ["", "## Two-view triangulation (`bench.py --triangulate 8000000 --steps 20`, inputs resident in HBM)", "",
             "* %d correspondences: %.3g correspondences/s, kernel %.0f us per launch (HIP events)" % (t["n"], t["value"], t["kernel_us"]),
             "* algorithmic 64 B per correspondence -> %.0f GB/s = %.1f %% of the HBM peak: the kernel is bound by the fp64"
             " arithmetic of the Jacobi sweeps (about five sweeps of six column rotations per correspondence), not by memory" % (

@@ -39,6 +39,13 @@ def test_product_path_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src, f"{f} mentions the oracle"
+    # nor may the helper scripts: only tests/, the smoke check and bench.py's CPU-baseline leg do
+    import re
+
+    for f in os.listdir(os.path.join(ROOT, "scripts")):
+        if f.endswith(".py"):
+            src = open(os.path.join(ROOT, "scripts", f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f"scripts/{f} imports the oracle"
 
 
 def test_status_codes_map_to_reference_exceptions():

@@ -273,7 +273,7 @@ def test_ladybug_scale_against_oracle(ba, visibility):
 
     At this size cond(S) is 1.4e9-2e9 and numpy's LU solution of S delta_a = e (what the
     reference and the oracle use) is itself 1e-9 relative away from the exact solution
-    (measured against an extended-precision refinement, see scripts/diag_solve.py); this
+    (measured against an extended-precision refinement, see tests/diag_solve.py); this
     step raises the cost by a factor of ~5, so that much solver noise moves the cost by
     ~4e-9 relative.  The bar is therefore 2e-8 on the cost here, 1e-7 on the updates, and the
     device solve must be at least as close to the extended-precision solution as LU is."""
