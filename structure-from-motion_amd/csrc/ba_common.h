@@ -16,9 +16,13 @@ constexpr int kPairChunk = 512;   // (obs, obs) entries per camera-pair work ite
 constexpr int kPairPad = 64;
 constexpr int kPairPartStride = 56;  // doubles per partial result of a split block: 7x7 block + e_j        // valid records / T rows kept behind the last entry
 
+// One (observation, observation) pair of a camera-pair block, as byte offsets (the kernel that walks
+// these adds a piece offset and issues the fetch; N * 112 < 2^32 is checked when the plan is built)
 struct PairEntry {
-  int32_t obs_a;  // observation (caller order) of the block's row camera j
-  int32_t obs_b;  // observation of the block's column camera k (same point)
+  uint32_t row_a;  // 112 * observation (caller order) of the block's row camera j: its row of A
+  uint32_t row_b;  // off the diagonal (j < k): 112 * observation of camera k, same point.  On the
+                   // diagonal the pair couples an observation with itself, row_b would repeat
+                   // row_a, and the field holds 16 * observation instead: its entry of g
 };
 
 }  // namespace sfmba

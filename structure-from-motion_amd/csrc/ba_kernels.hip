@@ -507,6 +507,27 @@ __device__ __forceinline__ void dma16(const void* base, unsigned off, unsigned l
       : "memory");
 }
 
+// Five such transfers with one save / restore of M0: four from `base` to LDS bytes lds_byte + 0,
+// 1024, 2048, 3072 and one from `base2` to lds_byte + 4096.  The five LDS addresses are formed by
+// the compiler and handed in as scalars: the statement itself touches no status bit.
+__device__ __forceinline__ void dma16x5(const void* base, unsigned o0, unsigned o1, unsigned o2, unsigned o3,
+                                        const void* base2, unsigned o4, unsigned lds_byte) {
+  unsigned keep;
+  const unsigned l1 = lds_byte + 1024u, l2 = lds_byte + 2048u, l3 = lds_byte + 3072u, l4 = lds_byte + 4096u;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6\n\t"
+      "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
+      "s_mov_b32 m0, %10\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6\n\t"
+      "s_mov_b32 m0, %11\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %6\n\t"
+      "s_mov_b32 m0, %12\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %7\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "v"(o4), "s"(base), "s"(base2), "s"(lds_byte), "s"(l1), "s"(l2),
+        "s"(l3), "s"(l4)
+      : "memory");
+}
+
 // LDS byte address of a pointer into a __shared__ array, as a wave-uniform scalar
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)p);
@@ -558,20 +579,20 @@ __global__ __launch_bounds__(64) void k_pair_blocks(
     dma16(ent, 8u * (unsigned)(i0 + 2 * (lane & 7)), erec_b + 1024 * (q % kPairERing));
   };
   // rows and T of step q -> image q % kPairRing (5 transfers); needs the step's records in LDS
+  const bool diag = bj == bk;  // a diagonal block's records hold (row of A, entry of g), see PairEntry
   auto rdma = [&](int q) {
     const int32_t* er = erec + 256 * (q % kPairERing);
     const unsigned base = rows_b + kPairImgB * (q % kPairRing);
     const int2 ea = *reinterpret_cast<const int2*>(er + 2 * r0);
     const int2 eb = *reinterpret_cast<const int2*>(er + 2 * r1);
-    dma16(A, 112u * (unsigned)ea.x + 16u * c0, base);
-    dma16(A, 112u * (unsigned)eb.x + 16u * c1, base + 1024);
-    dma16(A, 112u * (unsigned)ea.y + 16u * c0, base + 2048);
-    dma16(A, 112u * (unsigned)eb.y + 16u * c1, base + 2048 + 1024);
     const int i0 = min(beg + kPairStep * q, last_base);
     // lanes 0..31: the 16 T rows; lanes 32..47 of a diagonal block: g of the step's 16 observations
-    unsigned off = t_off + 32u * (unsigned)(i0 + ((lane >> 1) & 15)) + 16u * (lane & 1);
-    if (with_e && lane >= 32 && lane < 48) off = 16u * (unsigned)er[2 * (lane - 32)];
-    dma16(gT, off, base + 4096);
+    unsigned toff = t_off + 32u * (unsigned)(i0 + ((lane >> 1) & 15)) + 16u * (lane & 1);
+    // (records past the item's end belong to the next block, whose second field is a row of A, not
+    // an entry of g: those lanes fetch g[0], which is never used)
+    if (with_e && lane >= 32 && lane < 48) toff = i0 + (lane - 32) < end ? (unsigned)er[2 * (lane - 32) + 1] : 0u;
+    dma16x5(A, (unsigned)ea.x + 16u * c0, (unsigned)eb.x + 16u * c1, (unsigned)(diag ? ea.x : ea.y) + 16u * c0,
+            (unsigned)(diag ? eb.x : eb.y) + 16u * c1, gT, toff, base);
   };
   double acc0[7] = {0, 0, 0, 0, 0, 0, 0}, acc1[7] = {0, 0, 0, 0, 0, 0, 0};
   double e0 = 0.0, e1 = 0.0;

@@ -187,8 +187,8 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
           const int32_t sa = pt_ptr[i] + a, sb = pt_ptr[i] + b;
           int64_t& at = cnt[(size_t)slot_cam[sa] * m + slot_cam[sb]];
           PairEntry en;
-          en.obs_a = perm[sa];
-          en.obs_b = perm[sb];
+          en.row_a = 112u * (uint32_t)perm[sa];
+          en.row_b = sa == sb ? 16u * (uint32_t)perm[sa] : 112u * (uint32_t)perm[sb];
           pair_entry[(size_t)tp_ptr[i] + a * k - a * (a - 1) / 2 + (b - a)] = (int32_t)at;
           entries[(size_t)at++] = en;
         }
