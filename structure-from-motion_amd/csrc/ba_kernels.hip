@@ -264,7 +264,6 @@ __global__ __launch_bounds__(256) void k_point(
     double* __restrict__ eps_b, double* __restrict__ g, double* __restrict__ T) {
   __shared__ double sBp[kGroupSlots * 6];
   __shared__ double sCon[kGroupSlots * 9];
-  __shared__ double sVz[kGroupSlots * 9];
   __shared__ int sPtr[kGroupSlots + 1];
   __shared__ int sLp[kGroupSlots];
   const int t = threadIdx.x;
@@ -329,7 +328,9 @@ __global__ __launch_bounds__(256) void k_point(
     const double det = v00 * c00 + v01 * c01 + v02 * c02;
     const double id = 1.0 / det;
     const double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id, i11 = c11 * id, i12 = c12 * id, i22 = c22 * id;
-    double* vz = sVz + 9 * t;
+    // V^-1 and V^-1 eps_b of the point go where the contributions of its first observation were:
+    // only this thread has read them
+    double* vz = sCon + 9 * (sPtr[t] - s0);
     vz[0] = i00; vz[1] = i01; vz[2] = i02; vz[3] = i11; vz[4] = i12; vz[5] = i22;
     vz[6] = i00 * a[6] + i01 * a[7] + i02 * a[8];
     vz[7] = i01 * a[6] + i11 * a[7] + i12 * a[8];
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256) void k_point(
   __syncthreads();
   if (t < ns) {
     const int lp = sLp[t];
-    const double* vz = sVz + 9 * lp;
+    const double* vz = sCon + 9 * (sPtr[lp] - s0);
     const double i00 = vz[0], i01 = vz[1], i02 = vz[2], i11 = vz[3], i12 = vz[4], i22 = vz[5];
     const double z0 = vz[6], z1 = vz[7], z2 = vz[8];
     st2(g + 2 * (int64_t)pos, we[0] - (bp[0] * z0 + bp[1] * z1 + bp[2] * z2),
@@ -360,18 +361,27 @@ __global__ __launch_bounds__(256) void k_point(
     const int k = sPtr[lp + 1] - sPtr[lp];
     const int a = t - first;
     int64_t ts = (int64_t)tp_ptr[p0 + lp] + (int64_t)a * k - (int64_t)a * (a - 1) / 2;
-    for (int b = a; b < k; ++b, ++ts) {
-      const double* q = sBp + 6 * (first + b);
-      double* o = T + 4 * (int64_t)pair_entry[ts];  // row of T = position of the pair's entry
-      double t00 = h00 * q[0] + h01 * q[1] + h02 * q[2], t01 = h00 * q[3] + h01 * q[4] + h02 * q[5];
-      double t10 = h10 * q[0] + h11 * q[1] + h12 * q[2], t11 = h10 * q[3] + h11 * q[4] + h12 * q[5];
-      if (fold_u && b == a) {
-        // the observation's own pair also carries its term of U_j = sum A^T w A: the camera-pair
-        // kernel then produces U_j - sum Y W^T for the diagonal blocks by itself
-        t00 -= w00; t01 -= w01; t10 -= w10; t11 -= w11;
+    // four pairs at a time: their entry positions are fetched together, then the four rows go out
+    for (int b0 = a; b0 < k; b0 += 4, ts += 4) {
+      int pe[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pe[u] = b0 + u < k ? pair_entry[ts + u] : -1;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int b = b0 + u;
+        if (b >= k) break;
+        const double* q = sBp + 6 * (first + b);
+        double* o = T + 4 * (int64_t)pe[u];  // row of T = position of the pair's entry
+        double t00 = h00 * q[0] + h01 * q[1] + h02 * q[2], t01 = h00 * q[3] + h01 * q[4] + h02 * q[5];
+        double t10 = h10 * q[0] + h11 * q[1] + h12 * q[2], t11 = h10 * q[3] + h11 * q[4] + h12 * q[5];
+        if (fold_u && b == a) {
+          // the observation's own pair also carries its term of U_j = sum A^T w A: the camera-pair
+          // kernel then produces U_j - sum Y W^T for the diagonal blocks by itself
+          t00 -= w00; t01 -= w01; t10 -= w10; t11 -= w11;
+        }
+        st2(o, t00, t01);
+        st2(o + 2, t10, t11);
       }
-      st2(o, t00, t01);
-      st2(o + 2, t10, t11);
     }
   }
 }
