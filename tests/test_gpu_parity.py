@@ -317,3 +317,46 @@ def test_ladybug_scale_against_oracle(ba, visibility):
     Rg, Tg, _, _ = prob.cameras()
     assert relerr(Rg, R) < 1e-8 and relerr(Tg, T) < 1e-8
     assert relerr(prob.points(), X) < 1e-8
+
+
+def test_maximum_views_and_ragged_shapes(ba):
+    """Edge shapes of the index structures against the CPU oracle: one point seen by 256 cameras
+    (SFM_BA_MAX_VIEWS: the point fills a workgroup's range and its block list has 32 896 pairs), points
+    with a single observation, camera counts that are not multiples of anything; 257 views are
+    refused with the library's too-big status."""
+    from oracle import ba_oracle as orc
+    from sfm_amd import _lib, synthetic
+    from sfm_amd.device import DeviceProblem
+
+    rng = np.random.default_rng(4)
+    m, n = 256, 40
+    K = synthetic.K_DEFAULT
+    X_gt = rng.uniform(-1, 1, size=(n, 3)) + np.array([0, 0, 8.0])
+    R_gt = synthetic.rodrigues(rng.normal(0, 0.05, size=(m, 3)))
+    T_gt = -np.einsum("mij,mj->mi", R_gt, rng.normal(0, 0.3, size=(m, 3)))
+    pt, cam = [], []
+    for i in range(n):
+        if i == 0:
+            cams = np.arange(m)                      # the maximum
+        elif i < 8:
+            cams = rng.choice(m, size=1)             # single observations
+        else:
+            cams = np.sort(rng.choice(m, size=int(rng.integers(2, 60)), replace=False))
+        pt += [i] * len(cams)
+        cam += list(cams)
+    p = synthetic.observe_and_perturb(rng, K, R_gt, T_gt, X_gt, np.asarray(pt), np.asarray(cam))
+    prob = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true, check=False, n_cams=m)
+    R, T, X = p.R.copy(), p.T.copy(), p.X.copy()
+    c_ref, da_ref, db_ref = orc.gn_iteration_arrays(p.K, R, T, X, p.cam_idx, p.pt_idx, p.x_true)
+    prob.iterate_async()
+    prob.check_flags()
+    c = float(prob.cost_buf.item())
+    assert abs(c - c_ref) <= 1e-8 * c_ref
+    assert relerr(prob.delta_b.cpu().numpy(), db_ref) < 1e-6
+    assert relerr(prob.points(), X) < 1e-8
+
+    # 257 views of one point
+    cam2 = np.concatenate([np.arange(257), np.arange(257)]).astype(np.int32)
+    pt2 = np.concatenate([np.zeros(257), np.ones(257)]).astype(np.int32)
+    with pytest.raises(_lib.SfmBaError):
+        ba.dev.Plan(cam2, pt2)
