@@ -1,25 +1,26 @@
-// Reduced camera system: blocked right-looking Cholesky of the dense symmetric positive definite
-// matrix S (n x n, row-major, leading dimension n, lower triangle referenced) with the right-hand
-// side carried as row n of the same buffer, so that the forward substitution L y = e happens as
-// part of the panel solves.  Then a blocked backward substitution L^T x = y.
+// Reduced camera system S x = e, S symmetric positive definite (n x n, row-major, leading dimension
+// n, lower triangle referenced), right-hand side in row n of the same buffer.  Three paths share one
+// 64 x 64 diagonal-block factorisation (diag_core):
 //
-// Per panel of NB = 64 columns:
-//   k_chol_diag   : one workgroup factors the 64 x 64 diagonal block.  The block is handled as
-//                   4 x 4 sub-blocks of 16: a 16 x 16 sub-block is factored by one wave in
-//                   registers (row per lane, cross-lane reads instead of LDS round trips and
-//                   workgroup barriers), the rows under it are solved one lane per row, the rest
-//                   is updated from LDS.
-//                   Its inverse (needed by the panel kernel) is built from the four 16 x 16
-//                   inverses (one wave each) and small products on the matrix cores.
+// General path - blocked right-looking Cholesky, NB = 64, in place.  The right-hand side is carried
+// as row n, so the forward substitution L y = e happens as part of the panel solves; then a blocked
+// backward substitution L^T x = y.  Per panel:
+//   k_chol_diag   : first panel only: one workgroup factors and inverts the 64 x 64 diagonal block.
 //   k_chol_panel  : rows below the block (and the right-hand-side row) times inv(L_kk)^T   [MFMA]
 //                   All-zero 64-row tiles are flagged and skipped here and in the two kernels
 //                   below: S is block sparse whenever far-apart cameras share no point, and the
 //                   factor keeps those zeros outside the profile.
 //   k_chol_update : trailing lower-triangle tiles  A_ij -= P_i P_j^T                        [MFMA]
-//                   and, in the workgroup of tile (0, 0), the diagonal work of the next panel
+//                   The workgroup of tile (0, 0) keeps its result on chip and factors it: the
+//                   diagonal work of the next panel needs no launch of its own.
 //   k_chol_back   : one step of L^T x = y per panel, last panel first.
-// The update kernel uses v_mfma_f64_16x16x4_f64: a 64 x 64 output tile per workgroup, one 32 x 32
-// quadrant (2 x 2 MFMA tiles) per wave, operands staged in LDS with a row stride of 66 doubles
+//
+// Narrow band (no non-zero further than 64 places from the diagonal; S is then block tridiagonal
+// in 64 x 64 blocks and is only read):
+//   k_bcr_*       : block cyclic reduction - log2(n / 64) rounds of parallel eliminations.
+//   k_chol_band   : fewer than four blocks - one workgroup walks the chain in a single launch.
+//
+// Tile products use v_mfma_f64_16x16x4_f64 with operands staged in LDS at a row stride of 66 doubles
 // (conflict-free for the one-double-per-lane operand reads).
 #include "ba_common.h"
 
