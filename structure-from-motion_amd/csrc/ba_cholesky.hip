@@ -972,8 +972,9 @@ __global__ __launch_bounds__(256) void k_bcr_eliminate(int n, int np, int s, int
   }
 }
 
-// one workgroup per (remaining block, task): j = 2 (blockIdx >> 1), i = j s.  Task 0 updates D_i and
-// e_i from the eliminated neighbours on both sides; task 1 forms the new coupling S(i + 2s, i).
+// Eight workgroups per remaining block i = 2 (blockIdx >> 3) s: task (blockIdx >> 2) & 1, block row
+// q = blockIdx & 3 of the 64 x 64 result, one 16 x 16 tile per wave.  Task 0 updates D_i and e_i from
+// the eliminated neighbours on both sides; task 1 forms the new coupling S(i + 2s, i).
 __global__ __launch_bounds__(256) void k_bcr_update(int n, int np, int s, double* __restrict__ Dk,
                                                     double* __restrict__ Bk, const double* __restrict__ Pu,
                                                     const double* __restrict__ Pd, double* __restrict__ ek) {
@@ -981,30 +982,27 @@ __global__ __launch_bounds__(256) void k_bcr_update(int n, int np, int s, double
   __shared__ double Ta[NB * LDT];
   __shared__ double Tb[NB * LDT];
   __shared__ double ya[NB], yb[NB];
-  __shared__ double part[4][NB];
+  __shared__ double part[4][SB];
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int li = lane & 15, lk = lane >> 4;
-  const int i = 2 * ((int)blockIdx.x >> 1) * s;
-  const int task = blockIdx.x & 1;
+  const int i = 2 * ((int)blockIdx.x >> 3) * s;
+  const int task = (blockIdx.x >> 2) & 1;
+  const int q = blockIdx.x & 3;  // block row of the result
   const int o1 = i - s, o2 = i + s;
   const bool has1 = o1 >= 0, has2 = o2 < np;
   if (task == 1) {
-    // S(i + 2s, i) = -P_d[o2] P_u[o2]^T
+    // S(i + 2s, i) = -P_d[o2] P_u[o2]^T: tile (q, wave)
     if (!has2 || i + 2 * s >= np) return;
     tile_to_lds(Pd + (int64_t)o2 * NB * NB, Ta, t);
     tile_to_lds(Pu + (int64_t)o2 * NB * NB, Tb, t);
     __syncthreads();
     double* Bout = Bk + (int64_t)i * NB * NB;
+    d4_t c4 = {0.0, 0.0, 0.0, 0.0};
+    tile_mma(Ta, false, q, Tb, wave, NS, true, li, lk, c4);
 #pragma unroll
-    for (int I = 0; I < NS; ++I) {
-      const int J = (wave - I) & 3;
-      d4_t c4 = {0.0, 0.0, 0.0, 0.0};
-      tile_mma(Ta, false, I, Tb, J, NS, true, li, lk, c4);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) Bout[(I * SB + lk + 4 * g) * NB + J * SB + li] = c4[g];
-    }
+    for (int g = 0; g < 4; ++g) Bout[(q * SB + lk + 4 * g) * NB + wave * SB + li] = c4[g];
     return;
   }
   if (!has1 && !has2) return;
@@ -1025,31 +1023,29 @@ __global__ __launch_bounds__(256) void k_bcr_update(int n, int np, int s, double
   }
   __syncthreads();
   double* Di = Dk + (int64_t)i * NB * NB;
-  // lower blocks (I, J), J <= I; wave w owns those with (I + J) mod 4 = w
+  // lower tiles (q, wave), wave <= q
+  if (wave <= q) {
+    d4_t c4;
 #pragma unroll
-  for (int I = 0; I < NS; ++I)
+    for (int g = 0; g < 4; ++g) c4[g] = Di[(q * SB + lk + 4 * g) * NB + wave * SB + li];
+    if (has1) tile_mma(Ta, false, q, Ta, wave, NS, true, li, lk, c4);
+    if (has2) tile_mma(Tb, false, q, Tb, wave, NS, true, li, lk, c4);
 #pragma unroll
-    for (int J = 0; J <= I; ++J)
-      if (((I + J) & 3) == wave) {
-        d4_t c4;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) c4[g] = Di[(I * SB + lk + 4 * g) * NB + J * SB + li];
-        if (has1) tile_mma(Ta, false, I, Ta, J, NS, true, li, lk, c4);
-        if (has2) tile_mma(Tb, false, I, Tb, J, NS, true, li, lk, c4);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) Di[(I * SB + lk + 4 * g) * NB + J * SB + li] = c4[g];
-      }
-  // e_i -= P_d[o1] y_o1 + P_u[o2] y_o2
+    for (int g = 0; g < 4; ++g) Di[(q * SB + lk + 4 * g) * NB + wave * SB + li] = c4[g];
+  }
+  // rows 16 q .. 16 q + 15 of e_i -= P_d[o1] y_o1 + P_u[o2] y_o2: thread (row r, column quarter cq)
   {
-    const int r = t & 63, q = t >> 6;
-    double sacc = 0.0;
+    const int r = t & 15, cq = (t >> 4) & 3;
+    if (t < 64) {
+      double sacc = 0.0;
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
-      sacc += Ta[r * LDT + 16 * q + c] * ya[16 * q + c] + Tb[r * LDT + 16 * q + c] * yb[16 * q + c];
-    part[q][r] = sacc;
+      for (int c = 0; c < 16; ++c)
+        sacc += Ta[(q * SB + r) * LDT + 16 * cq + c] * ya[16 * cq + c] + Tb[(q * SB + r) * LDT + 16 * cq + c] * yb[16 * cq + c];
+      part[cq][r] = sacc;
+    }
   }
   __syncthreads();
-  if (t < NB) ek[i * NB + t] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+  if (t < SB) ek[i * NB + q * SB + t] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
 }
 
 // x_i = inv(L_i)^T (y_i - P_u^T x_u - P_d^T x_d) for the blocks eliminated at stride s
@@ -1142,7 +1138,7 @@ int launch_solve_band_packed(double* packed, int n, double mu_diag, double* da, 
   for (; s < np; s *= 2) {
     const int m = (np + s - 1) / s;  // active blocks 0, s, 2s, ...
     hipLaunchKernelGGL(k_bcr_eliminate, dim3(m / 2), dim3(256), 0, st, n, np, s, 1, Dk, Bk, Pu, Pd, ek, info);
-    hipLaunchKernelGGL(k_bcr_update, dim3(2 * ((m + 1) / 2)), dim3(256), 0, st, n, np, s, Dk, Bk, Pu, Pd, ek);
+    hipLaunchKernelGGL(k_bcr_update, dim3(8 * ((m + 1) / 2)), dim3(256), 0, st, n, np, s, Dk, Bk, Pu, Pd, ek);
   }
   // block 0 is what is left: no neighbours at this stride
   hipLaunchKernelGGL(k_bcr_eliminate, dim3(1), dim3(256), 0, st, n, np, s, 0, Dk, Bk, Pu, Pd, ek, info);
