@@ -548,7 +548,7 @@ constexpr int kPairStep = 16;  // entries per step
 // pieces (2 KiB), then T [16][4] padded to 64 pieces (1 KiB)
 constexpr int kPairImgB = 5120;
 constexpr int kPairRing = 2;   // row images
-constexpr int kPairERing = 3;  // entry-record slots (1 KiB each, 128 B used)
+constexpr int kPairERing = 4;  // entry-record slots (1 KiB each, 128 B used); a power of two: q % 4 is a mask
 
 __global__ __launch_bounds__(64) void k_pair_blocks(
     int n_items, const int32_t* __restrict__ pit_blk, const int32_t* __restrict__ pit_beg,
@@ -606,20 +606,22 @@ __global__ __launch_bounds__(64) void k_pair_blocks(
   };
   double acc0[7] = {0, 0, 0, 0, 0, 0, 0}, acc1[7] = {0, 0, 0, 0, 0, 0, 0};
   double e0 = 0.0, e1 = 0.0;
-  auto consume = [&](int q) {
+  // `tail`: the step may reach past the item's last entry (only the last step can)
+  auto consume = [&](int q, bool tail) {
     const int i0 = beg + kPairStep * q;
     const double* ba = rows + (kPairImgB / 8) * (q % kPairRing);
     const double* bb = ba + 256;
     const double* bt = ba + 512 + 4 * g;
     double2 t0 = ld2(bt), t1 = ld2(bt + 2);
-    if (i0 + g >= end) t0 = t1 = make_double2(0.0, 0.0);  // past the item's last entry
+    const bool dead = tail && i0 + g >= end;
+    if (dead) t0 = t1 = make_double2(0.0, 0.0);
     const double2 b0 = ld2(bb + 14 * g + 2 * h);  // A_b[0][2h], A_b[0][2h+1]
     const double b10 = bb[14 * g + 7 + 2 * h], b11 = bb[14 * g + 8 + 2 * h];
     const double p00 = t0.x * b0.x + t0.y * b10, p10 = t1.x * b0.x + t1.y * b10;
     const double p01 = t0.x * b0.y + t0.y * b11, p11 = t1.x * b0.y + t1.y * b11;
     if (with_e) {
       double2 gv = ld2(ba + 512 + 64 + 2 * g);
-      if (i0 + g >= end) gv = make_double2(0.0, 0.0);
+      if (dead) gv = make_double2(0.0, 0.0);
       e0 = fma(b10, gv.y, fma(b0.x, gv.x, e0));
       e1 = fma(b11, gv.y, fma(b0.y, gv.x, e1));
     }
@@ -644,13 +646,15 @@ __global__ __launch_bounds__(64) void k_pair_blocks(
   edma(2);
   rdma(1);
   edma(3);
-  for (int s = 0; s < nsteps; ++s) {
+  for (int s = 0; s < nsteps - 1; ++s) {
     // all but the 6 youngest transfers have landed: the rows of step s, the records of step s+2
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    consume(s);
+    consume(s, false);
     rdma(s + 2);  // into the image just consumed
     edma(s + 4);
   }
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  consume(nsteps - 1, true);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be landing when the LDS is released
 #pragma unroll
   for (int r = 0; r < 7; ++r) {
