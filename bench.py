@@ -171,10 +171,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
+    # Rehearsal on a box with fewer GPUs than ranks: SFM_BA_BENCH_BACKEND=gloo puts every rank on
+    # GPU 0 and moves the buffers with gloo (RCCL refuses two ranks on one device).  The numbers of
+    # such a run mean nothing; it exists to exercise the multi-rank code path.
+    backend = os.environ.get("SFM_BA_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+    else:
+        torch.cuda.set_device(0)
     group = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     m, n_per_gpu, k = synthetic.WORKLOADS[args.workload]
