@@ -174,6 +174,7 @@ class DeviceProblem:
         # sharded run with a narrow band: what the ranks all-reduce (see assemble)
         self.band_sharded = self.sharded and self.half_bandwidth <= 64
         self._packed_mu = None
+        self._s_holds_foreign = False
         if self.band_sharded:
             self.packed = torch.empty((int(self.lib.sfm_ba_band_packed_elements(n7)),), dtype=F64, device=d)
         self.cost_buf = torch.zeros((1,), dtype=F64, device=d)
@@ -207,6 +208,10 @@ class DeviceProblem:
         # from ``self.packed``.
         reduce_packed = bool(reduce_packed) and self.band_sharded
         self._packed_mu = float(mu) if reduce_packed else None
+        if reduce_packed and self._s_holds_foreign:
+            # an earlier dense exchange left other ranks' sums in blocks this rank never writes
+            self.sys[: (n7 + 1) * n7].zero_()
+            self._s_holds_foreign = False
         if (self.plan.n_blocks < self.m * (self.m + 1) // 2 and not reduce_packed
                 and (self.sharded or self.half_bandwidth > 64)):
             # camera pairs without a shared point are not written by the kernels; the previous
@@ -229,6 +234,7 @@ class DeviceProblem:
         elif self.sharded:
             import torch.distributed as dist
 
+            self._s_holds_foreign = True
             dist.all_reduce(self.sys[: (n7 + 1) * n7], group=self.group)
             _lib.check(self.lib.sfm_ba_add_diagonal(p(self.S), n7, float(mu), _stream()))
             self.e.copy_(self.S[n7].view(self.m, 7))

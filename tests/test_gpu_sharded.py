@@ -105,6 +105,10 @@ def test_forced_sharded_flow_single_rank():
             b = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true, group=dist.group.WORLD,
                               sharded=True)
             assert b.band_sharded == packed
+            # a dense exchange first (the by-hand API), then the loop's packed one: must not mix up
+            b.camera_prepare()
+            b.jacobian()
+            b.assemble(0.5)
             ca = a.run(max_iter=3, threshold=0.0)
             cb = b.run(max_iter=3, threshold=0.0)
             assert np.max(np.abs(np.asarray(ca) - np.asarray(cb)) / np.asarray(ca)) < 1e-10
