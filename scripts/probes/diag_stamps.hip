@@ -69,7 +69,6 @@ int main() {
   for (int kk = 0; kk < 4; ++kk)
     printf(" kk=%d factor %lld  barrier %lld  jobs %lld  barrier %lld\n", kk, st[2 + 4 * kk] - st[1 + 4 * kk],
            st[3 + 4 * kk] - st[2 + 4 * kk], st[4 + 4 * kk] - st[3 + 4 * kk], (kk < 3 ? st[5 + 4 * kk] : st[16]) - st[4 + 4 * kk]);
-  printf(" kk=1 detail: loads %lld  factor16 %lld  stores %lld  rest-to-stamp %lld\n", st[40] - st[5], st[41] - st[40], st[42] - st[41], st[6] - st[42]);
   printf(" loop %lld, tail jobs %lld, barrier %lld, stores %lld, all %lld\n", st[16] - st[0], st[17] - st[16], st[18] - st[17], st[19] - st[18], st[19] - st[0]);
   // check: L L^T = S and invL L = I
   std::vector<double> Lh((n + 1) * n), Ih(64 * 64);
@@ -85,38 +84,5 @@ int main() {
       e2 = fmax(e2, fabs(s2 - (i == j ? 1.0 : 0.0)));
     }
   printf(" max |L L^T - S| = %.3e   max |invL L - I| = %.3e\n", e1, e2);
-  {
-    // band chain: 8 panels, half bandwidth 48
-    const int nn = 512, hb = 48;
-    std::vector<double> B((nn + 1) * nn, 0.0);
-    for (int i = 0; i < nn; ++i) {
-      double rs = 0;
-      for (int j = 0; j < nn; ++j)
-        if (i != j && abs(i - j) <= hb) { B[i * nn + j] = 0.01 * ((i * 7 + j * 13) % 11 - 5); B[i * nn + j] = B[j * nn + i] = 0.01 * (((i < j ? i : j) * 7 + (i < j ? j : i) * 13) % 11 - 5); }
-      for (int j = 0; j < nn; ++j) rs += fabs(B[i * nn + j]);
-      B[i * nn + i] = rs + 1.0;
-      B[nn * nn + i] = 1.0;
-    }
-    double *dB, *dws, *dx;
-    (void)hipMalloc(&dB, B.size() * 8); (void)hipMalloc(&dws, (8 * 4096 * 2 + 8 * 64 + 64) * 8); (void)hipMalloc(&dx, nn * 8);
-    (void)hipMemcpy(dB, B.data(), B.size() * 8, hipMemcpyHostToDevice);
-    for (int rep = 0; rep < 3; ++rep) {
-      sfmba::k_chol_band<<<1, 256>>>(dB, nn, dws, dws + 8 * 4096 + 8 * 64 + 64, dws + 8 * 4096, dx, dinfo);
-      (void)hipDeviceSynchronize();
-    }
-    (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(sfmba::g_stamps), sizeof(st));
-    printf("band panel 1: prefetch issue %lld, diag_core %lld, fwd+Bt write+sync %lld, P mfma %lld, P store+sync %lld, PP^T mfma %lld, D write+sync %lld\n",
-           st[21] - st[20], st[22] - st[21], st[23] - st[22], st[24] - st[23], st[25] - st[24], st[26] - st[25], st[27] - st[26]);
-    for (int kk = 0; kk < 4; ++kk)
-      printf(" band kk=%d factor %lld  barrier %lld  jobs %lld  barrier %lld\n", kk, st[2 + 4 * kk] - st[1 + 4 * kk],
-             st[3 + 4 * kk] - st[2 + 4 * kk], st[4 + 4 * kk] - st[3 + 4 * kk], (kk < 3 ? st[5 + 4 * kk] : st[16]) - st[4 + 4 * kk]);
-    printf(" band tail jobs %lld, barrier+fold %lld, stores %lld\n", st[17] - st[16], st[18] - st[17], st[19] - st[18]);
-    printf("band: diag_core internal loop %lld; backward sweep of 8 panels %lld\n", st[16] - st[0], st[29] - st[28]);
-    std::vector<double> xh(nn);
-    (void)hipMemcpy(xh.data(), dx, nn * 8, hipMemcpyDeviceToHost);
-    double rmax = 0;
-    for (int i = 0; i < nn; ++i) { double r = -1.0; for (int j = 0; j < nn; ++j) r += B[i * nn + j] * xh[j]; rmax = fmax(rmax, fabs(r)); }
-    printf("band residual max %.3e\n", rmax);
-  }
   return 0;
 }

@@ -36,31 +36,13 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // diagonal factorisation; the library build compiles the stamps away.
 #ifdef SFMBA_STAMPS
 __device__ long long g_stamps[48];
-__device__ int g_stamp_on = 1;
 #define STAMP(i)                                                   \
   do {                                                             \
-    if (threadIdx.x == 0 && g_stamp_on) g_stamps[i] = (long long)__builtin_amdgcn_s_memtime(); \
-  } while (0)
-#define STAMP_GATE(on) \
-  do {                 \
-    if (threadIdx.x == 0) g_stamp_on = (on); \
-  } while (0)
-// stamp ordered after `dep` is produced and before its later uses
-#define STAMP_DEP(i, dep)                                                                              \
-  do {                                                                                                 \
-    long long t_;                                                                                      \
-    asm volatile("s_nop 0\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(dep)::"memory"); \
-    if (threadIdx.x == 0) g_stamps[i] = t_;                                                            \
+    if (threadIdx.x == 0) g_stamps[i] = (long long)__builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define STAMP(i) \
   do {           \
-  } while (0)
-#define STAMP_DEP(i, dep) \
-  do {                    \
-  } while (0)
-#define STAMP_GATE(on) \
-  do {                 \
   } while (0)
 #endif
 
@@ -228,15 +210,12 @@ __device__ __forceinline__ void diag_core(double* __restrict__ L, double* __rest
         a[c] = from_l ? L[row * LDT + o + c] : 0.0;
         if (wave == 1 && lane - SB == c) a[c] = 1.0;
       }
-      if (kk == 1) STAMP_DEP(40, a[15]);
       const int bad = factor16(a, lane);
-      if (kk == 1) STAMP_DEP(41, a[15]);
       if (wave == 0) {
         if (row < NB) {
 #pragma unroll
           for (int c = 0; c < SB; ++c) L[row * LDT + o + c] = a[c];
         }
-        if (kk == 1) STAMP(42);
         if (bad && lane == 0 && o + bad <= nb) atomicCAS(info, 0, k0 + o + bad);
       } else if (lane >= SB && lane < 2 * SB) {
         // lane 16 + q holds row q of inv(L_kk)^T
@@ -646,8 +625,6 @@ __global__ __launch_bounds__(256) void k_chol_band(const double* __restrict__ S,
     const bool has_next = k + 1 < np;
     const int k1 = k0 + NB;
     const int nb1 = has_next ? ((n - k1) < NB ? (n - k1) : NB) : 0;
-    STAMP_GATE(k == 1);
-    STAMP(20);
     // waves 2 and 3, while waves 0 and 1 factor the first block column: the tile below the diagonal
     // block (with the mask of its non-zero 16 x 16 blocks), the next diagonal block, the next piece
     // of the right-hand side
@@ -689,9 +666,7 @@ __global__ __launch_bounds__(256) void k_chol_band(const double* __restrict__ S,
         if (tt < NB) en[tt] = ev;
       }
     };
-    STAMP(21);
     diag_core(D, X, nullptr, n, k0, nb, invL_ws + (int64_t)k * NB * NB, info, fetch_next);
-    STAMP(22);
     // forward substitution of this panel: y_k = inv(L_kk) tv
     {
       const int r = t & 63, q = t >> 6;
@@ -707,7 +682,6 @@ __global__ __launch_bounds__(256) void k_chol_band(const double* __restrict__ S,
       y_ws[k0 + t] = yk;
     }
     if (!has_next) break;
-    STAMP(23);
     // P = B inv(L_kk)^T.  Wave w owns the four blocks (I, (w - I) mod 4); block (I, J) sums over block
     // columns kb <= J (inv(L) is lower triangular) in which B has a non-zero block.
     const unsigned bmask = bmask_sh;
@@ -725,7 +699,6 @@ __global__ __launch_bounds__(256) void k_chol_band(const double* __restrict__ S,
       pacc[I] = d4_t{0.0, 0.0, 0.0, 0.0};
       block_prod(Bt, I, (bmask >> (4 * I)) & 15u, X, J, 15u, J + 1, false, li, lk, pacc[I]);
     }
-    STAMP(24);
     __syncthreads();  // every wave is done reading Bt (and yv is visible)
     double* pk = p_ws + (int64_t)k * NB * NB;
 #pragma unroll
@@ -740,7 +713,6 @@ __global__ __launch_bounds__(256) void k_chol_band(const double* __restrict__ S,
     }
     if (t == 0) bmask_sh = 0u;  // for the next panel's fetch (a barrier away from its first use)
     __syncthreads();
-    STAMP(25);
     // next diagonal block -= P P^T, lower blocks only: wave w owns the blocks (I, J), J <= I, with
     // (I + J) mod 4 = w; next tv = e - P y
 #pragma unroll
@@ -756,7 +728,6 @@ __global__ __launch_bounds__(256) void k_chol_band(const double* __restrict__ S,
             for (int g = 0; g < 4; ++g) Dn[(I * SB + lk + 4 * g) * LDT + J * SB + li] += c4[g];
           }
         }
-    STAMP(26);
     {
       const int r = t & 63, q = t >> 6;
       double sacc = 0.0;
@@ -765,13 +736,10 @@ __global__ __launch_bounds__(256) void k_chol_band(const double* __restrict__ S,
       part[q][r] = sacc;
     }
     __syncthreads();
-    STAMP(27);
     if (t < NB) tv[t] = en[t] - ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t]));
     // (diag_core opens with a workgroup barrier: Dn and tv are visible to every wave after it)
   }
   __syncthreads();
-  STAMP_GATE(1);
-  STAMP(28);
   // backward substitution, last panel first: x_k = inv(L_kk)^T (y_k - P_k^T x_{k+1}); yv holds y of the
   // last panel already.  Thread (col = t & 63, rq = t >> 6) sums rows rq, rq+4, ... of its column.
   const int col = t & 63, rq = t >> 6;
@@ -823,7 +791,6 @@ __global__ __launch_bounds__(256) void k_chol_band(const double* __restrict__ S,
     }
     __syncthreads();
   }
-  STAMP(29);
 }
 
 // ---- band path, parallel form: block cyclic reduction -----------------------------------------
