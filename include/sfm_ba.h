@@ -73,7 +73,23 @@ typedef struct sfm_ba_plan sfm_ba_plan;
 
 int sfm_ba_plan_create(const int32_t* h_cam_idx, const int32_t* h_pt_idx, int64_t n_obs,
                        int32_t n_cams_hint, int32_t n_pts_hint, int check, sfm_ba_plan** out_plan);
+/* The same plan (array for array) built on the device from index lists that already sit in device
+ * memory: the per-call index work of `get_indices` (src/bundle_adjustment.py:44-67) and
+ * `Indices.__init__` (src/sparse_ba.py:58-97) as two radix sorts and a few prefix sums, without
+ * the host pass and the upload of the finished plan.  Same checks, same return codes.  Allocates
+ * temporary device memory (about 24 bytes per pair entry) and returns after `stream` has drained. */
+int sfm_ba_plan_create_device(const int32_t* d_cam_idx, const int32_t* d_pt_idx, int64_t n_obs,
+                              int32_t n_cams_hint, int32_t n_pts_hint, int check, void* stream,
+                              sfm_ba_plan** out_plan);
 void sfm_ba_plan_destroy(sfm_ba_plan* plan);
+/* Copies one index array of the plan to the host (for tools and tests; the reference exposes the
+ * same information as attributes of `Indices`, src/sparse_ba.py:64-97).  field: 0 pt_ptr, 1 perm,
+ * 2 slot_cam, 3 tp_ptr, 4 pair_entry, 5 grp_pt, 6 cam_obs (empty when the caller order is
+ * camera-sorted), 7-9 per-camera items (camera, begin, end), 10 cam_item_ptr, 11-12 block cameras
+ * (j, k), 13 pair entries (two uint32 each), 14-17 pair items (block, begin, end, partial), 18-20
+ * split blocks (block, first partial, partials).  *bytes receives the array's size; h_dst may be
+ * null to query it, otherwise `capacity` must be at least that size. */
+int sfm_ba_plan_read(const sfm_ba_plan* plan, int field, void* h_dst, int64_t capacity, int64_t* bytes);
 /* sizes: what[0]=n_cams, [1]=n_pts, [2]=n_obs, [3]=number of camera-pair blocks (j<=k) with a shared
  * point, [4]=number of (obs,obs) pair entries, [5]=number of per-point pair slots (doubles/4 of d_T),
  * [6]=number of per-camera work items, [7]=bytes of device memory held by the plan */

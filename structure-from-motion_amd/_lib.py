@@ -27,6 +27,8 @@ SYMBOLS = {
     "sfm_ba_last_hip_error": (C.c_char_p, []),
     "sfm_ba_plan_create": (_int, [_vp, _vp, _i64, _i32, _i32, _int, C.POINTER(_vp)]),
     "sfm_ba_plan_destroy": (None, [_vp]),
+    "sfm_ba_plan_create_device": (_int, [_vp, _vp, _i64, _i32, _i32, _int, _vp, C.POINTER(_vp)]),
+    "sfm_ba_plan_read": (_int, [_vp, _int, _vp, _i64, C.POINTER(_i64)]),
     "sfm_ba_plan_sizes": (_int, [_vp, C.POINTER(_i64)]),
     "sfm_ba_plan_workspace_bytes": (_i64, [_vp]),
     "sfm_ba_camera_prepare": (_int, [_vp, _vp, _vp, _int, _i32, _vp, _vp, _vp]),

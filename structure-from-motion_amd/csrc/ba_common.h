@@ -73,6 +73,7 @@ struct sfm_ba_plan {
 namespace sfmba {
 
 void set_hip_error(hipError_t err, const char* what);
+void plan_set_workspace(sfm_ba_plan* p);  // workspace section offsets from the plan's counts
 
 // per-kernel timing (ba_profile.cpp): a ProfScope around a launch records two events on the
 // launch stream while profiling is enabled, and costs one branch otherwise

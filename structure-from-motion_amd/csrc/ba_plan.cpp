@@ -30,6 +30,20 @@ static int upload(const std::vector<T>& h, T** d, int64_t* bytes) {
 
 static inline int64_t align256(int64_t v) { return (v + 255) & ~int64_t(255); }
 
+// workspace section offsets (bytes) from the plan's counts
+void plan_set_workspace(sfm_ba_plan* p) {
+  int64_t off = 0;
+  p->ws_g = off;
+  off = align256(off + p->n_obs * 2 * (int64_t)sizeof(double));
+  p->ws_T = off;
+  off = align256(off + (p->n_pair_slots + kPairPad) * 4 * (int64_t)sizeof(double));
+  p->ws_campart = off;
+  off = align256(off + (int64_t)std::max(p->n_items, 1) * SFM_BA_CAM_RED * (int64_t)sizeof(double));
+  p->ws_spart = off;
+  off = align256(off + (int64_t)std::max(p->n_parts, 1) * kPairPartStride * (int64_t)sizeof(double));
+  p->ws_total = off;
+}
+
 }  // namespace sfmba
 
 using namespace sfmba;
@@ -114,18 +128,20 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   p->n_obs = N;
 
   // ---- per-point pair slots and workgroup ranges ----
+  // A point takes max(k, 1) units; it opens a new workgroup range when its first unit falls into
+  // another window of kGroupSlots - kmax + 1 units than its predecessor's.  A range then holds at
+  // most kGroupSlots observations and at most kGroupSlots points, and the rule needs no sequential
+  // pass (the device builder applies it with a prefix sum).
   std::vector<int32_t> tp_ptr(n + 1, 0), grp_pt;
   int64_t pairs = 0;
   {
-    int32_t in_group = 0;
-    grp_pt.push_back(0);
+    const int32_t window = kGroupSlots - std::max(kmax, 1) + 1;
+    int64_t unit = 0, prev_unit = 0;
     for (int32_t i = 0; i < n; ++i) {
       const int32_t k = pt_ptr[i + 1] - pt_ptr[i];
-      if (in_group + k > kGroupSlots) {
-        grp_pt.push_back(i);
-        in_group = 0;
-      }
-      in_group += k;
+      if (i == 0 || unit / window != prev_unit / window) grp_pt.push_back(i);
+      prev_unit = unit;
+      unit += std::max(k, 1);
       tp_ptr[i] = (int32_t)pairs;
       pairs += (int64_t)k * (k + 1) / 2;
       // 32-bit byte offsets into T, counted from the start of g that precedes it in the workspace
@@ -255,17 +271,7 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   }
   p->device_bytes = bytes;
 
-  // ---- workspace sections ----
-  int64_t off = 0;
-  p->ws_g = off;
-  off = align256(off + N * 2 * (int64_t)sizeof(double));
-  p->ws_T = off;
-  off = align256(off + (pairs + kPairPad) * 4 * (int64_t)sizeof(double));
-  p->ws_campart = off;
-  off = align256(off + (int64_t)std::max(p->n_items, 1) * SFM_BA_CAM_RED * (int64_t)sizeof(double));
-  p->ws_spart = off;
-  off = align256(off + (int64_t)std::max(n_parts, 1) * kPairPartStride * (int64_t)sizeof(double));
-  p->ws_total = off;
+  plan_set_workspace(p);
   *out = p;
   return SFM_BA_OK;
 }
@@ -280,6 +286,41 @@ extern "C" int sfm_ba_plan_sizes(const sfm_ba_plan* p, int64_t what[8]) {
   what[5] = p->n_pair_slots;
   what[6] = p->n_items;
   what[7] = p->device_bytes;
+  return SFM_BA_OK;
+}
+
+extern "C" int sfm_ba_plan_read(const sfm_ba_plan* p, int field, void* h_dst, int64_t capacity, int64_t* bytes_out) {
+  if (!p || !bytes_out) return SFM_BA_EINVAL;
+  const void* src = nullptr;
+  int64_t count = 0, width = sizeof(int32_t);
+  switch (field) {
+    case 0: src = p->d_pt_ptr; count = p->n + 1; break;
+    case 1: src = p->d_perm; count = p->n_obs; break;
+    case 2: src = p->d_slot_cam; count = p->n_obs; break;
+    case 3: src = p->d_tp_ptr; count = p->n + 1; break;
+    case 4: src = p->d_pair_entry; count = p->n_pair_slots; break;
+    case 5: src = p->d_grp_pt; count = p->n_groups + 1; break;
+    case 6: src = p->d_cam_obs; count = p->d_cam_obs ? p->n_obs : 0; break;
+    case 7: src = p->d_item_cam; count = p->n_items; break;
+    case 8: src = p->d_item_beg; count = p->n_items; break;
+    case 9: src = p->d_item_end; count = p->n_items; break;
+    case 10: src = p->d_cam_item_ptr; count = p->m + 1; break;
+    case 11: src = p->d_blk_j; count = p->n_blocks; break;
+    case 12: src = p->d_blk_k; count = p->n_blocks; break;
+    case 13: src = p->d_entries; count = p->n_entries + kPairPad; width = sizeof(PairEntry); break;
+    case 14: src = p->d_pit_blk; count = p->n_pair_items; break;
+    case 15: src = p->d_pit_beg; count = p->n_pair_items; break;
+    case 16: src = p->d_pit_end; count = p->n_pair_items; break;
+    case 17: src = p->d_pit_part; count = p->n_pair_items; break;
+    case 18: src = p->d_mb_blk; count = p->n_multi; break;
+    case 19: src = p->d_mb_part; count = p->n_multi; break;
+    case 20: src = p->d_mb_cnt; count = p->n_multi; break;
+    default: return SFM_BA_EINVAL;
+  }
+  *bytes_out = count * width;
+  if (!h_dst) return SFM_BA_OK;
+  if (capacity < count * width) return SFM_BA_EINVAL;
+  if (count > 0) SFMBA_HIP(hipMemcpy(h_dst, src, (size_t)(count * width), hipMemcpyDeviceToHost));
   return SFM_BA_OK;
 }
 

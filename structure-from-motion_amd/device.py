@@ -34,18 +34,42 @@ def _stream():
 
 
 class Plan:
-    """Owner of a ``sfm_ba_plan`` handle (index structures of one visibility pattern)."""
+    """Owner of a ``sfm_ba_plan`` handle (index structures of one visibility pattern).
 
-    def __init__(self, cam_idx, pt_idx, n_cams_hint=0, n_pts_hint=0, check=True):
+    ``cam_idx`` / ``pt_idx``: int32 index lists, either host arrays or tensors on the GPU.  With
+    ``where="device"`` (default) the plan is built on the GPU from the device copies; with
+    ``where="host"`` by the host builder, which then uploads it.  Both produce the same arrays.
+    """
+
+    FIELDS = ("pt_ptr", "perm", "slot_cam", "tp_ptr", "pair_entry", "grp_pt", "cam_obs", "item_cam", "item_beg",
+              "item_end", "cam_item_ptr", "blk_j", "blk_k", "entries", "pit_blk", "pit_beg", "pit_end", "pit_part",
+              "mb_blk", "mb_part", "mb_cnt")
+
+    def __init__(self, cam_idx, pt_idx, n_cams_hint=0, n_pts_hint=0, check=True, where="device"):
         lib = _lib.load()
-        cam = np.ascontiguousarray(cam_idx, dtype=np.int32)
-        pt = np.ascontiguousarray(pt_idx, dtype=np.int32)
-        assert cam.shape == pt.shape and cam.ndim == 1
-        _dev()
+        dev = _dev()
         handle = C.c_void_p()
-        rc = lib.sfm_ba_plan_create(
-            cam.ctypes.data_as(C.c_void_p), pt.ctypes.data_as(C.c_void_p), cam.shape[0],
-            int(n_cams_hint), int(n_pts_hint), int(bool(check)), C.byref(handle))
+        if where == "host":
+            if torch.is_tensor(cam_idx):
+                cam_idx, pt_idx = cam_idx.cpu().numpy(), pt_idx.cpu().numpy()
+            cam = np.ascontiguousarray(cam_idx, dtype=np.int32)
+            pt = np.ascontiguousarray(pt_idx, dtype=np.int32)
+            assert cam.shape == pt.shape and cam.ndim == 1
+            rc = lib.sfm_ba_plan_create(
+                cam.ctypes.data_as(C.c_void_p), pt.ctypes.data_as(C.c_void_p), cam.shape[0],
+                int(n_cams_hint), int(n_pts_hint), int(bool(check)), C.byref(handle))
+        elif where == "device":
+            if not torch.is_tensor(cam_idx):
+                cam_idx = torch.from_numpy(np.ascontiguousarray(cam_idx, dtype=np.int32)).to(dev)
+                pt_idx = torch.from_numpy(np.ascontiguousarray(pt_idx, dtype=np.int32)).to(dev)
+            assert cam_idx.is_cuda and pt_idx.is_cuda and cam_idx.dtype == I32 and pt_idx.dtype == I32
+            assert cam_idx.is_contiguous() and pt_idx.is_contiguous()
+            assert cam_idx.shape == pt_idx.shape and cam_idx.dim() == 1
+            rc = lib.sfm_ba_plan_create_device(
+                _lib.ptr(cam_idx), _lib.ptr(pt_idx), cam_idx.shape[0], int(n_cams_hint), int(n_pts_hint),
+                int(bool(check)), _stream(), C.byref(handle))
+        else:
+            raise ValueError("where must be 'device' or 'host'")
         _lib.check(rc)
         self._lib = lib
         self.handle = handle
@@ -55,6 +79,16 @@ class Plan:
          self.n_items, self.device_bytes) = [int(v) for v in sizes]
         self.workspace_bytes = int(lib.sfm_ba_plan_workspace_bytes(handle))
         self.half_bandwidth = int(lib.sfm_ba_plan_half_bandwidth(handle))
+
+    def read(self, field):
+        """One index array of the plan as a host array (``entries``: uint32 (n, 2))."""
+        idx = self.FIELDS.index(field)
+        nbytes = C.c_int64()
+        _lib.check(self._lib.sfm_ba_plan_read(self.handle, idx, None, 0, C.byref(nbytes)))
+        out = np.empty(nbytes.value // 4, dtype=np.uint32 if field == "entries" else np.int32)
+        _lib.check(self._lib.sfm_ba_plan_read(self.handle, idx, out.ctypes.data_as(C.c_void_p), out.nbytes,
+                                              C.byref(nbytes)))
+        return out.reshape(-1, 2) if field == "entries" else out
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -79,7 +113,7 @@ class DeviceProblem:
     X_STEP = 0.5   # :100
 
     def __init__(self, K, R, T, X, cam_idx, pt_idx, x_true, n_cams=None, group=None, check=True, device=None,
-                 sharded=None):
+                 sharded=None, plan_where="device"):
         self.lib = _lib.load()
         self.device = _dev(device)
         self.group = group
@@ -101,8 +135,12 @@ class DeviceProblem:
         self.N = int(cam_idx.shape[0])
         sharded = self.sharded
         hinted = sharded or not check
-        self.plan = Plan(cam_idx, pt_idx, n_cams_hint=self.m if hinted else 0,
-                         n_pts_hint=self.n if hinted else 0, check=check)
+        with torch.cuda.device(self.device):
+            self.cam_idx = torch.from_numpy(cam_idx).to(self.device)
+            self.pt_idx = torch.from_numpy(pt_idx).to(self.device)
+            self.plan = Plan(self.cam_idx if plan_where == "device" else cam_idx,
+                             self.pt_idx if plan_where == "device" else pt_idx, n_cams_hint=self.m if hinted else 0,
+                             n_pts_hint=self.n if hinted else 0, check=check, where=plan_where)
         if self.plan.m != self.m or self.plan.n != self.n:
             # the reference's Indices asserts that every id up to the maximum occurs
             raise AssertionError("index lists do not cover every camera / point")
@@ -133,8 +171,6 @@ class DeviceProblem:
         P = Kb @ np.concatenate([R, T[:, :, None]], axis=2)
         self.P = torch.from_numpy(np.ascontiguousarray(P).reshape(-1, 12)).to(d)
         self.X = torch.from_numpy(X.copy()).to(d)
-        self.cam_idx = torch.from_numpy(cam_idx).to(d)
-        self.pt_idx = torch.from_numpy(pt_idx).to(d)
         self.x_true = torch.from_numpy(np.ascontiguousarray(x_true, dtype=np.float64).reshape(-1, 2)).to(d)
         self._alloc()
 
