@@ -24,14 +24,20 @@ def _pack_frames(frames):
 
 
 def _flatten(frames):
-    """Frame-major observation lists (src/bundle_adjustment.py:50-63)."""
-    vi, pi, xt = [], [], [np.zeros((0, 2))]
-    for frame_n, frame in enumerate(frames):
+    """Frame-major observation lists (src/bundle_adjustment.py:50-63) as arrays: viewpoint index
+    and point index (int32) and the observed pixels (N, 2).  The frames' index lists are converted
+    once each; nothing is built element by element."""
+    for frame in frames:
         assert len(frame.triangulated_idx) == len(frame.index_kp_3d)
-        vi.extend([frame_n] * len(frame.triangulated_idx))
-        pi.extend(frame.index_kp_3d)
-        xt.append(np.asarray(frame.keypoints)[frame.triangulated_idx][:, :2])
-    return vi, pi, np.vstack(xt)
+    counts = np.fromiter((len(f.index_kp_3d) for f in frames), dtype=np.int64, count=len(frames))
+    vi = np.repeat(np.arange(len(frames), dtype=np.int32), counts)
+    pi = [np.zeros(0, dtype=np.int32)]
+    xt = [np.zeros((0, 2))]
+    for frame in frames:
+        pi.append(np.asarray(frame.index_kp_3d, dtype=np.int32).reshape(-1))
+        idx = np.asarray(frame.triangulated_idx, dtype=np.intp).reshape(-1)
+        xt.append(np.asarray(frame.keypoints)[idx][:, :2])
+    return vi, np.concatenate(pi), np.vstack(xt)
 
 
 def _problem_from(frames, map_, check=True):
@@ -53,9 +59,9 @@ def get_indices(frames, map_):
     K, R, T, C, P = _pack_frames(frames)
     vi, pi, x_t = _flatten(frames)
     if len(vi) == 0:
-        return vi, pi, x_t, np.zeros((0, 2))
+        return [], [], x_t, np.zeros((0, 2))
     _, _, x_p = jacobian_blocks(K, R, C, np.asarray(map_.X)[:, :3], vi, pi, P=P)
-    return vi, pi, x_t, x_p
+    return vi.tolist(), pi.tolist(), x_t, x_p  # the reference returns lists
 
 
 def compute_A_B(frames, map_, viewpoints_indices, point_indices):
