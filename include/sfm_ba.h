@@ -253,6 +253,37 @@ int sfm_ba_triangulate(const double* d_x1, const double* d_x2, const double* d_P
                        int64_t n, float* d_Xh, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Linear PnP: pose of a camera from 3D-2D correspondences, the other producer of the poses bundle
+ * adjustment starts from.  sfm_ba_pnp_solve does the work of `estimate_pose_Linear_PnP_n`
+ * (src/pose_estimation.py:73-105) or `estimate_pose_Linear_PnP` (:41-70) for n_hyp subsets of the
+ * correspondences at once - the 200 minimal samples of `estimate_pose_Linear_PnP_RANSAC`
+ * (:108-144) are one call - and sfm_ba_pnp_inliers counts, per pose, the correspondences that
+ * reproject within the threshold (:123-133).
+ *   d_x [n,3] homogeneous pixels, d_X [n,4] homogeneous points (fp64)
+ *   d_Kinv_pre  [9] or NULL : K^-1 applied to x before the rows are built       (:85, PnP_n)
+ *   d_Kinv_post [9] or NULL : K^-1 applied to the recovered 3x4 matrix          (:34, PnP)
+ *   d_idx [n_hyp, n_per_hyp] rows of d_x / d_X each hypothesis uses, or NULL for 0..n_per_hyp-1
+ *   d_workspace : sfm_ba_pnp_workspace_bytes(n_hyp, n_per_hyp) bytes
+ *   d_R [n_hyp,9], d_T [n_hyp,3] out: rotation (det +1) and translation after `cleanup_RT_mat`
+ *   (:21-30); d_flags [n_hyp] out: 1 where det(U V^T) rounds to neither +1 nor -1 (the reference
+ *   then fails with an unassigned result)
+ *   sfm_ba_pnp_inliers: d_K [9]; d_counts [n_hyp] out; d_mask [n_hyp, n] bytes out or NULL
+ * The right singular vector comes from one-sided Jacobi rotations on the stacked rows (blocks of
+ * 192 rows, reduced by orthogonal transformations only), not from the normal equations.
+ * ---------------------------------------------------------------------------------------- */
+int64_t sfm_ba_pnp_workspace_bytes(int32_t n_hyp, int32_t n_per_hyp);
+int sfm_ba_pnp_solve(const double* d_x, const double* d_X, const double* d_Kinv_pre, const double* d_Kinv_post,
+                     const int32_t* d_idx, int32_t n_hyp, int32_t n_per_hyp, void* d_workspace, double* d_R,
+                     double* d_T, int32_t* d_flags, void* stream);
+/* `cleanup_RT_mat` / `decompose_projection_mat` alone (src/pose_estimation.py:21-38) for n 3x4
+ * matrices d_RT [n,12] row-major (K^-1 applied first when d_Kinv_post is given) */
+int sfm_ba_pnp_cleanup(const double* d_RT, const double* d_Kinv_post, int32_t n, double* d_R, double* d_T,
+                       int32_t* d_flags, void* stream);
+int sfm_ba_pnp_inliers(const double* d_x, const double* d_X, const double* d_K, const double* d_R,
+                       const double* d_T, int32_t n_hyp, int64_t n, double threshold, int32_t* d_counts,
+                       uint8_t* d_mask, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel timing (no counterpart in the reference, which has no profiler).  While enabled,
  * every kernel launch made by the entry points above is bracketed by two HIP events recorded on
  * the launch stream; sfm_ba_profile_read waits for them, adds the elapsed milliseconds and launch

@@ -41,6 +41,10 @@ SYMBOLS = {
     "sfm_ba_solve_reduced_banded": (_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "sfm_ba_plan_half_bandwidth": (_i32, [_vp]),
     "sfm_ba_triangulate": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "sfm_ba_pnp_workspace_bytes": (_i64, [_i32, _i32]),
+    "sfm_ba_pnp_solve": (_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "sfm_ba_pnp_cleanup": (_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "sfm_ba_pnp_inliers": (_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, C.c_double, _vp, _vp, _vp]),
     "sfm_ba_band_packed_elements": (_i64, [_i32]),
     "sfm_ba_band_pack": (_int, [_vp, _i32, _vp, _vp]),
     "sfm_ba_solve_band_packed": (_int, [_vp, _i32, _f64, _vp, _vp, _vp, _vp]),

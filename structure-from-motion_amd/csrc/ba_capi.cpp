@@ -79,6 +79,31 @@ int sfm_ba_triangulate(const double* d_x1, const double* d_x2, const double* d_P
   return launch_triangulate(d_x1, d_x2, d_P1, d_P2, n, d_Xh, static_cast<hipStream_t>(stream));
 }
 
+int64_t sfm_ba_pnp_workspace_bytes(int32_t n_hyp, int32_t n_per_hyp) {
+  return n_hyp > 0 && n_per_hyp > 0 ? pnp_workspace_bytes(n_hyp, n_per_hyp) : 0;
+}
+
+int sfm_ba_pnp_solve(const double* d_x, const double* d_X, const double* d_Kinv_pre, const double* d_Kinv_post,
+                     const int32_t* d_idx, int32_t n_hyp, int32_t n_per_hyp, void* d_workspace, double* d_R, double* d_T,
+                     int32_t* d_flags, void* stream) {
+  if (!d_x || !d_X || !d_workspace || !d_R || !d_T || !d_flags || n_hyp <= 0 || n_per_hyp <= 0) return SFM_BA_EINVAL;
+  return launch_pnp_solve(d_x, d_X, d_Kinv_pre, d_Kinv_post, d_idx, n_hyp, n_per_hyp, d_workspace, d_R, d_T, d_flags,
+                          static_cast<hipStream_t>(stream));
+}
+
+int sfm_ba_pnp_cleanup(const double* d_RT, const double* d_Kinv_post, int32_t n, double* d_R, double* d_T,
+                       int32_t* d_flags, void* stream) {
+  if (!d_RT || !d_R || !d_T || !d_flags || n <= 0) return SFM_BA_EINVAL;
+  return launch_pnp_cleanup(d_RT, d_Kinv_post, n, d_R, d_T, d_flags, static_cast<hipStream_t>(stream));
+}
+
+int sfm_ba_pnp_inliers(const double* d_x, const double* d_X, const double* d_K, const double* d_R, const double* d_T,
+                       int32_t n_hyp, int64_t n, double threshold, int32_t* d_counts, uint8_t* d_mask, void* stream) {
+  if (!d_x || !d_X || !d_K || !d_R || !d_T || !d_counts) return SFM_BA_EINVAL;
+  return launch_pnp_inliers(d_x, d_X, d_K, d_R, d_T, n_hyp, n, threshold, d_counts, d_mask,
+                            static_cast<hipStream_t>(stream));
+}
+
 int64_t sfm_ba_band_packed_elements(int32_t n7) { return n7 > 0 ? band_packed_elements(n7) : 0; }
 
 int sfm_ba_band_pack(const double* d_S, int32_t n7, double* d_packed, void* stream) {

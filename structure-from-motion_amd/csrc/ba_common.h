@@ -137,4 +137,14 @@ int launch_solve_band_packed(double* packed, int n7, double mu_diag, double* da,
 int launch_triangulate(const double* x1, const double* x2, const double* P1, const double* P2, int64_t n, float* Xh,
                        hipStream_t st);
 
+int64_t pnp_workspace_bytes(int n_hyp, int s);
+int launch_pnp_solve(const double* x, const double* X, const double* Kinv_pre, const double* Kinv_post,
+                     const int32_t* idx, int n_hyp, int s, void* ws, double* R, double* T, int32_t* flags,
+                     hipStream_t st);
+int launch_pnp_cleanup(const double* RT, const double* Kinv_post, int n, double* R, double* T, int32_t* flags,
+                       hipStream_t st);
+int launch_pnp_inliers(const double* x, const double* X, const double* K, const double* R, const double* T, int n_hyp,
+                       int64_t n, double threshold, int32_t* counts, uint8_t* mask, hipStream_t st);
+
+
 }  // namespace sfmba
