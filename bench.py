@@ -142,6 +142,51 @@ def triangulation_line(n, reps):
         "max_rel_diff_vs_oracle": err}))
 
 
+def pnp_line(n, reps):
+    """`--pnp N`: the reference's RANSAC pose estimation (200 minimal samples, inlier counts, refit) on N
+    3D-2D correspondences, whole call including sampling and transfers, and the numpy oracle beside it."""
+    import torch
+
+    import sfm_amd  # noqa: F401
+    from sfm_amd import pose_estimation as pe, synthetic
+
+    rng = np.random.default_rng(0)
+    K = synthetic.K_DEFAULT
+    R = synthetic.rodrigues(np.array([0.3, -0.2, 0.1]))
+    T = np.array([[0.2], [-0.1], [7.0]])
+    X = np.concatenate([rng.uniform(-2, 2, size=(n, 3)), np.ones((n, 1))], axis=1)
+    x = K @ np.hstack([R, T]) @ X.T
+    x = (x / x[-1]).T
+    x[:, :2] += rng.normal(0, 0.5, size=(n, 2))
+    bad = rng.random(n) < 0.3
+    x[bad, :2] += rng.uniform(-300, 300, size=(int(bad.sum()), 2))
+    np.random.seed(1)
+    pe.estimate_pose_Linear_PnP_RANSAC(x, X, K, threshold=8.0)
+    torch.cuda.synchronize()
+    np.random.seed(1)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        Rg, Tg, ng = pe.estimate_pose_Linear_PnP_RANSAC(x, X, K, threshold=8.0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    from oracle import pnp_oracle as orc
+
+    np.random.seed(1)
+    t1 = time.perf_counter()
+    Ro, To, no = orc.estimate_pose_Linear_PnP_RANSAC(x, X, K, threshold=8.0)
+    tc = time.perf_counter() - t1
+    np.random.seed(1)
+    Rg, Tg, ng = pe.estimate_pose_Linear_PnP_RANSAC(x, X, K, threshold=8.0)
+    print(json.dumps({
+        "metric": "RANSAC linear PnP, pose estimations/s", "n": n, "value": 1.0 / dt, "unit": "calls/s",
+        "ms_per_call": dt * 1e3, "dtype": "f64", "data": "synthetic, 30 % outliers",
+        "cpu_baseline": {"value": 1.0 / tc, "unit": "calls/s", "cores": 1, "kind": "port",
+                         "sample": f"numpy oracle, one call on the same {n} correspondences in {tc:.2f} s"},
+        "inliers": int(ng), "inliers_oracle": int(no),
+        "max_rel_diff_vs_oracle": float(max(np.max(np.abs(Rg - Ro)) / np.max(np.abs(Ro)),
+                                            np.max(np.abs(Tg - To)) / np.max(np.abs(To))))}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,7 +198,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--triangulate", type=int, default=0, metavar="N",
                     help="benchmark the two-view triangulation kernel on N correspondences instead")
+    ap.add_argument("--pnp", type=int, default=0, metavar="N",
+                    help="benchmark RANSAC linear PnP on N correspondences instead")
     args = ap.parse_args()
+    if args.pnp > 0:
+        pnp_line(args.pnp, max(args.steps, 1))
+        return
     if args.triangulate > 0:
         triangulation_line(args.triangulate, max(args.steps, 1))
         return

@@ -15,4 +15,8 @@ for W in "ladybug50 banded" "ladybug50 uniform" "c4_500x300k uniform" "venice180
   set -- $W
   timeout -k 10 400 python3 bench.py --workload $1 --visibility $2 --no-cpu-baseline > gpurun_out/${TAG}_bench_$1_$2.json 2> gpurun_out/${TAG}_bench_$1_$2.err || exit 5
 done
+timeout -k 10 300 python3 bench.py --triangulate 8000000 --steps 20 > gpurun_out/${TAG}_triangulate.json 2> gpurun_out/${TAG}_triangulate.err || exit 6
+timeout -k 10 300 python3 bench.py --pnp 20000 --steps 10 > gpurun_out/${TAG}_pnp.json 2> gpurun_out/${TAG}_pnp.err || exit 7
+timeout -k 10 300 python3 scripts/time_setup.py > gpurun_out/${TAG}_setup.txt 2>&1 || exit 8
+timeout -k 10 300 python3 scripts/time_dropin.py c4_500x300k > gpurun_out/${TAG}_dropin.txt 2>&1 || exit 9
 echo evidence done

@@ -87,11 +87,26 @@ if os.path.exists(tri):
                 t["roofline"]["achieved"], 100 * t["roofline"]["frac"]),
             "* CPU baseline (`kind: port`): %.3g correspondences/s — %s" % (t["cpu_baseline"]["value"], t["cpu_baseline"]["sample"]),
             "* largest difference from the oracle after rounding to float32: %.1e of the largest coordinate" % t["max_rel_diff_vs_oracle"]]
+pnp = os.path.join(P, f"{tag}_pnp.json")
+if os.path.exists(pnp):
+    t = json.loads(open(pnp).read().strip().splitlines()[-1])
+    out += ["", "## RANSAC linear PnP (`bench.py --pnp 20000 --steps 10`, whole call from host arrays)", "",
+            "* %d correspondences, 200 minimal samples + inlier counts + refit on %d inliers: %.1f ms per call" % (
+                t["n"], t["inliers"], t["ms_per_call"]),
+            "* CPU baseline (`kind: port`): %.3g calls/s - %s" % (t["cpu_baseline"]["value"], t["cpu_baseline"]["sample"]),
+            "* inliers %d (oracle %d); largest difference of the pose from the oracle: %.1e" % (
+                t["inliers"], t["inliers_oracle"], t["max_rel_diff_vs_oracle"])]
+for name, title in (("setup", "Handing a problem over as host arrays (`scripts/time_setup.py`, default workload)"),
+                    ("dropin", "Drop-in `optimize_using_BA(frames, map_)`, 10 iterations (`scripts/time_dropin.py c4_500x300k`)")):
+    path = os.path.join(P, f"{tag}_{name}.txt")
+    if os.path.exists(path):
+        out += ["", "## " + title, "", "```"] + [line.rstrip() for line in open(path)] + ["```"]
 out += ["", "## Files", "",
         f"* `{tag}_bench_*.json` — the JSON line of each bench run",
         f"* `{tag}_c4_banded_kernel_stats.csv`, `{tag}_c4_banded_kernel_summary.txt` — rocprofv3 kernel statistics of the default bench",
         f"* `{tag}_c4_banded_pmc_fetch_size.txt`, `{tag}_c4_banded_pmc_write_size.txt`, `{tag}_pmc_traffic.json` — PMC passes",
-        f"* `{tag}_triangulate.json` — triangulation benchmark line",
+        f"* `{tag}_triangulate.json`, `{tag}_pnp.json` — triangulation and PnP benchmark lines",
+        f"* `{tag}_setup.txt`, `{tag}_dropin.txt` — host-side timings of plan build / uploads and of the drop-in call",
         f"* `{tag}_c4_banded_baseline_kernel_stats.csv` — the first working version of this round (9.4 ms per iteration), for comparison",
         ""]
 open(os.path.join(P, "README.md"), "w").write("\n".join(out))
