@@ -216,6 +216,11 @@ def main():
     from sfm_amd.device import DeviceProblem
     from sfm_amd.dist import local_problem, packed_system_elements
 
+    if os.environ.get("SFM_BA_BENCH_WATCHDOG"):
+        # a rank that is still running after this many seconds prints where every thread stands and exits
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["SFM_BA_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -247,7 +252,8 @@ def main():
         prob_h = full
     del full
     prob = DeviceProblem(prob_h.K, prob_h.R, prob_h.T, prob_h.X, prob_h.cam_idx, prob_h.pt_idx, prob_h.x_true,
-                         n_cams=m, group=group, check=(world == 1))
+                         n_cams=m, group=group, check=(world == 1),
+                         plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"))
     N_loc, n_loc = prob.N, prob.n
 
     def barrier():

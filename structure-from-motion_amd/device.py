@@ -174,6 +174,18 @@ class DeviceProblem:
         self.x_true = torch.from_numpy(np.ascontiguousarray(x_true, dtype=np.float64).reshape(-1, 2)).to(d)
         self._alloc()
 
+    def _all_reduce(self, t):
+        """Sum a device buffer over the group, in place.  RCCL reduces it where it lies; any other
+        backend (gloo: CPU tests, rehearsals with several ranks on one GPU) gets a host copy."""
+        import torch.distributed as dist
+
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(t, group=self.group)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+
     # -- state that the reference keeps on frames / map ---------------------------------------
     def set_state(self, C=None, P=None):
         """Override the derived camera centre / projection (frames may carry their own)."""
@@ -266,12 +278,12 @@ class DeviceProblem:
 
             # blocks and right-hand-side entries this rank never writes stay zero from allocation
             _lib.check(self.lib.sfm_ba_band_pack(p(self.S), n7, p(self.packed), _stream()))
-            dist.all_reduce(self.packed, group=self.group)
+            self._all_reduce(self.packed)
         elif self.sharded:
             import torch.distributed as dist
 
             self._s_holds_foreign = True
-            dist.all_reduce(self.sys[: (n7 + 1) * n7], group=self.group)
+            self._all_reduce(self.sys[: (n7 + 1) * n7])
             _lib.check(self.lib.sfm_ba_add_diagonal(p(self.S), n7, float(mu), _stream()))
             self.e.copy_(self.S[n7].view(self.m, 7))
 
@@ -306,7 +318,7 @@ class DeviceProblem:
         if self.sharded:
             import torch.distributed as dist
 
-            dist.all_reduce(self.ssq, group=self.group)
+            self._all_reduce(self.ssq)
         _lib.check(self.lib.sfm_ba_cost_finish(p(self.ssq), self.m, p(self.cost_buf), _stream()))
 
     def cost(self) -> float:
