@@ -46,15 +46,23 @@ enum Stat {
 __global__ void k_idx_stats(const int32_t* __restrict__ cam, const int32_t* __restrict__ pt, int64_t N,
                             int32_t* __restrict__ stats) {
   const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
-  if (i >= N) return;
-  const int32_t c = cam[i], p = pt[i];
-  if (c < 0 || p < 0) {
-    stats[ST_NEGATIVE] = 1;
-    return;
+  const bool live = i < N;
+  int32_t c = live ? cam[i] : 0, p = live ? pt[i] : 0;
+  const bool negative = c < 0 || p < 0;
+  const bool unsorted = live && i > 0 && c < cam[i - 1];
+  // one atomic per wave and statistic: the maxima are reduced across the lanes first
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    c = max(c, __shfl_xor(c, s));
+    p = max(p, __shfl_xor(p, s));
   }
-  atomicMax(&stats[ST_MAX_CAM], c);
-  atomicMax(&stats[ST_MAX_PT], p);
-  if (i > 0 && c < cam[i - 1]) stats[ST_CAM_UNSORTED] = 1;
+  const bool any_negative = __any(negative), any_unsorted = __any(unsorted);
+  if ((threadIdx.x & 63) == 0) {
+    if (any_negative) stats[ST_NEGATIVE] = 1;
+    if (any_unsorted) stats[ST_CAM_UNSORTED] = 1;
+    atomicMax(&stats[ST_MAX_CAM], c);
+    atomicMax(&stats[ST_MAX_PT], p);
+  }
 }
 
 // histograms of camera and point ids; a wave whose lanes all carry one camera (the frame-major
@@ -185,12 +193,11 @@ __global__ void k_block_list(const int32_t* __restrict__ seen, const int32_t* __
 }
 
 // one thread per slot a of point i: its pairs (a, b >= a) get their block id as sort key, the pair
-// slot as value, the record the camera-pair kernel walks, and are counted per block
+// slot as value, and the record the camera-pair kernel walks
 __global__ void k_pair_keys(const int32_t* __restrict__ pt_ptr, const int32_t* __restrict__ tp_ptr,
                             const int32_t* __restrict__ slot_pt, const int32_t* __restrict__ slot_cam,
                             const int32_t* __restrict__ perm, const int32_t* __restrict__ blk_of, int64_t N, int32_t m,
-                            uint32_t* __restrict__ key, int32_t* __restrict__ val, PairEntry* __restrict__ rec,
-                            int32_t* __restrict__ blk_cnt) {
+                            uint32_t* __restrict__ key, int32_t* __restrict__ val, PairEntry* __restrict__ rec) {
   const int64_t s = (int64_t)blockIdx.x * kT + threadIdx.x;
   if (s >= N) return;
   const int32_t i = slot_pt[s];
@@ -206,7 +213,6 @@ __global__ void k_pair_keys(const int32_t* __restrict__ pt_ptr, const int32_t* _
     en.row_a = 112u * pa;
     en.row_b = b == a ? 16u * pa : 112u * (uint32_t)perm[first + b];
     rec[ts] = en;
-    atomicAdd(&blk_cnt[id], 1);
   }
 }
 
@@ -219,12 +225,21 @@ __global__ void k_place_entries(const int32_t* __restrict__ sorted_slot, const P
   pair_entry[ts] = (int32_t)pos;
 }
 
+// first entry of every block from the sorted keys (every block id occurs: a block exists because a
+// pair belongs to it); blk_ptr[nb] = number of entries
+__global__ void k_block_starts(const uint32_t* __restrict__ key, int64_t E, int32_t nb, int32_t* __restrict__ blk_ptr) {
+  const int64_t pos = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (pos >= E) return;
+  if (pos == 0 || key[pos] != key[pos - 1]) blk_ptr[key[pos]] = (int32_t)pos;
+  if (pos == E - 1) blk_ptr[nb] = (int32_t)E;
+}
+
 // per block: work items (chunks of kPairChunk entries), whether it is split, its partial results
-__global__ void k_block_chunks(const int32_t* __restrict__ blk_cnt, int32_t nb, int32_t* __restrict__ chunks,
+__global__ void k_block_chunks(const int32_t* __restrict__ blk_ptr, int32_t nb, int32_t* __restrict__ chunks,
                                int32_t* __restrict__ multi, int32_t* __restrict__ parts) {
   const int32_t b = blockIdx.x * kT + threadIdx.x;
   if (b > nb) return;
-  const int32_t ch = b < nb ? (blk_cnt[b] + kPairChunk - 1) / kPairChunk : 0;
+  const int32_t ch = b < nb ? (blk_ptr[b + 1] - blk_ptr[b] + kPairChunk - 1) / kPairChunk : 0;
   chunks[b] = ch;
   multi[b] = ch > 1 ? 1 : 0;
   parts[b] = ch > 1 ? ch : 0;
@@ -435,25 +450,23 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
 
   // ---- pair entries ordered by (block, point) ----
   uint32_t *pkey, *pkey_sorted;
-  int32_t *pval, *pval_sorted, *blk_cnt, *blk_ptr;
+  int32_t *pval, *pval_sorted, *blk_ptr;
   PairEntry* rec;
   SFMBA_HIP(scratch.get(&pkey, pairs));
   SFMBA_HIP(scratch.get(&pkey_sorted, pairs));
   SFMBA_HIP(scratch.get(&pval, pairs));
   SFMBA_HIP(scratch.get(&pval_sorted, pairs));
   SFMBA_HIP(scratch.get(&rec, pairs));
-  SFMBA_HIP(scratch.get(&blk_cnt, nb + 1));
   SFMBA_HIP(scratch.get(&blk_ptr, nb + 1));
-  SFMBA_HIP(hipMemsetAsync(blk_cnt, 0, sizeof(int32_t) * (nb + 1), st));
   k_pair_keys<<<blocks_for(N), kT, 0, st>>>(p->d_pt_ptr, p->d_tp_ptr, slot_pt, p->d_slot_cam, p->d_perm, blk_of, N, m, pkey,
-                                           pval, rec, blk_cnt);
+                                           pval, rec);
   SFMBA_TRY(sort_pairs(pkey, pkey_sorted, pval, pval_sorted, pairs, bits_for(nb), scratch, st));
   SFMBA_TRY(keep(&p->d_entries, pairs + kPairPad, &bytes));
   SFMBA_TRY(keep(&p->d_pair_entry, pairs, &bytes));
   // the camera-pair kernel fetches whole steps: valid (zero) records behind the last entry
   SFMBA_HIP(hipMemsetAsync(p->d_entries + pairs, 0, sizeof(PairEntry) * kPairPad, st));
   k_place_entries<<<blocks_for(pairs), kT, 0, st>>>(pval_sorted, rec, pairs, p->d_entries, p->d_pair_entry);
-  SFMBA_TRY(scan_exclusive(blk_cnt, blk_ptr, nb + 1, scratch, st));
+  k_block_starts<<<blocks_for(pairs), kT, 0, st>>>(pkey_sorted, pairs, nb, blk_ptr);
 
   // ---- pair work items and the partial results of split blocks ----
   int32_t *chunks, *multi, *parts, *item_off, *multi_off, *part_off;
@@ -463,7 +476,7 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
   parts = multi + (nb + 1);
   multi_off = item_off + (nb + 1);
   part_off = multi_off + (nb + 1);
-  k_block_chunks<<<blocks_for(nb + 1), kT, 0, st>>>(blk_cnt, nb, chunks, multi, parts);
+  k_block_chunks<<<blocks_for(nb + 1), kT, 0, st>>>(blk_ptr, nb, chunks, multi, parts);
   SFMBA_TRY(scan_exclusive(chunks, item_off, nb + 1, scratch, st));
   SFMBA_TRY(scan_exclusive(multi, multi_off, nb + 1, scratch, st));
   SFMBA_TRY(scan_exclusive(parts, part_off, nb + 1, scratch, st));
