@@ -323,6 +323,9 @@ def main():
             "frac": groups[dominant]["GBps"] / HBM_PEAK_GBS,
             "traffic": groups[dominant]["traffic"],
             "groups": groups,
+            "note": "algorithmic bytes count A and B as materialised arrays (184 / 200 / 168 bytes per observation "
+                    "for the three stages); the loop itself no longer writes B (dF/dX = -dF/dC is read from A), "
+                    "which would make them 136 / 152 / 120",
         }
         n7 = 7 * m
         solve_ms = prof.get("solve_reduced", (0.0, 1))[0] / args.steps

@@ -134,6 +134,9 @@ int sfm_ba_jacobian(const double* d_cam_blk, const double* d_P, const double* d_
  * Schur assembly.  Work of calc_U, calc_V_inv, calc_W, calc_Y, calc_S, calc_epsilon,
  * calc_epsilon_a, calc_epsilon_b and calc_e (src/sparse_ba.py:147-271) as called by
  * `SBA.compute` (src/sparse_ba.py:393-402).
+ *   d_B may be NULL here and in sfm_ba_back_substitute: the point block is then taken as minus
+ *   the camera-centre block of d_A (columns 4..6), which is what the reference's Jacobians satisfy
+ *   exactly (src/jacobian.py:29-49: dF/dC = -dF/dX); the loop then never materialises B.
  *   d_A [N,2,7], d_B [N,2,3], d_x_true [N,2], d_x_pred [N,2] in the observation order the plan
  *   was built from; d_weights [N,2,2] symmetric or NULL (identity, src/sparse_ba.py:387-388)
  *   mu     : damping added to every V_i (src/sparse_ba.py:206,210)

@@ -41,7 +41,7 @@ int sfm_ba_schur_assemble(const sfm_ba_plan* plan, const double* d_A, const doub
                           const double* d_x_pred, const double* d_weights, double mu, double mu_u, double* d_S,
                           double* d_e, double* d_U, double* d_eps_a, double* d_V_inv, double* d_eps_b,
                           double* d_cam_red, void* d_workspace, void* stream) {
-  if (!plan || !d_A || !d_B || !d_x_true || !d_x_pred || !d_V_inv || !d_eps_b || !d_workspace) return SFM_BA_EINVAL;
+  if (!plan || !d_A || !d_x_true || !d_x_pred || !d_V_inv || !d_eps_b || !d_workspace) return SFM_BA_EINVAL;
   if (!(mu >= 0.0) || !(mu_u >= 0.0)) return SFM_BA_EINVAL;
   return launch_assemble(plan, d_A, d_B, d_x_true, d_x_pred, d_weights, mu, mu_u, d_S, d_e, d_U, d_eps_a, d_V_inv,
                          d_eps_b, d_cam_red, d_workspace, static_cast<hipStream_t>(stream));
@@ -121,7 +121,7 @@ int sfm_ba_solve_band_packed(double* d_packed, int32_t n7, double mu_diag, doubl
 int sfm_ba_back_substitute(const sfm_ba_plan* plan, const double* d_A, const double* d_B, const double* d_weights,
                            const double* d_V_inv, const double* d_eps_b, const double* d_delta_a,
                            double* d_delta_b, double* d_X_update, double x_step, void* stream) {
-  if (!plan || !d_A || !d_B || !d_V_inv || !d_eps_b || !d_delta_a || !d_delta_b) return SFM_BA_EINVAL;
+  if (!plan || !d_A || !d_V_inv || !d_eps_b || !d_delta_a || !d_delta_b) return SFM_BA_EINVAL;
   return launch_back_substitute(plan, d_A, d_B, d_weights, d_V_inv, d_eps_b, d_delta_a, d_delta_b, d_X_update,
                                 x_step, static_cast<hipStream_t>(stream));
 }

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_jacobian(
 __global__ __launch_bounds__(256) void k_point(
     const int32_t* __restrict__ grp_pt, const int32_t* __restrict__ pt_ptr,
     const int32_t* __restrict__ perm, const int32_t* __restrict__ tp_ptr,
-    const int32_t* __restrict__ pair_entry,
+    const int32_t* __restrict__ pair_entry, const double* __restrict__ A,
     const double* __restrict__ B, const double* __restrict__ xt, const double* __restrict__ xpred,
     const double* __restrict__ wgt, double mu, int fold_u, double* __restrict__ Vinv,
     double* __restrict__ eps_b, double* __restrict__ g, double* __restrict__ T) {
@@ -281,9 +281,17 @@ __global__ __launch_bounds__(256) void k_point(
   int pos = 0;
   if (t < ns) {
     pos = perm[s0 + t];
-    const double* b = B + 6 * (int64_t)pos;
-    const double2 b01 = ld2(b), b23 = ld2(b + 2), b45 = ld2(b + 4);
-    const double bb[6] = {b01.x, b01.y, b23.x, b23.y, b45.x, b45.y};
+    double bb[6];
+    if (B) {
+      const double* b = B + 6 * (int64_t)pos;
+      const double2 b01 = ld2(b), b23 = ld2(b + 2), b45 = ld2(b + 4);
+      bb[0] = b01.x; bb[1] = b01.y; bb[2] = b23.x; bb[3] = b23.y; bb[4] = b45.x; bb[5] = b45.y;
+    } else {
+      // no B given: the point block is minus the camera-centre block of A (columns 4..6 of both rows)
+      const double* ap = A + 14 * (int64_t)pos;
+      const double2 a45 = ld2(ap + 4), a1213 = ld2(ap + 12);
+      bb[0] = -a45.x; bb[1] = -a45.y; bb[2] = -ap[6]; bb[3] = -ap[11]; bb[4] = -a1213.x; bb[5] = -a1213.y;
+    }
     const double2 xa = ld2(xt + 2 * (int64_t)pos), xb = ld2(xpred + 2 * (int64_t)pos);
     const double e0 = xa.x - xb.x, e1 = xa.y - xb.y;
     if (wgt) {
@@ -839,9 +847,15 @@ __global__ __launch_bounds__(256) void k_back_substitute(
       w00 = wp[0]; w01 = wp[1]; w10 = wp[2]; w11 = wp[3];
     }
     const double k0 = w00 * h0 + w01 * h1, k1 = w10 * h0 + w11 * h1;
-    const double* b = B + 6 * pos;
+    if (B) {
+      const double* b = B + 6 * pos;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) sV[3 * t + q] = b[q] * k0 + b[3 + q] * k1;
+      for (int q = 0; q < 3; ++q) sV[3 * t + q] = b[q] * k0 + b[3 + q] * k1;
+    } else {
+      // no B given: minus the camera-centre block of A
+#pragma unroll
+      for (int q = 0; q < 3; ++q) sV[3 * t + q] = -ap[4 + q] * k0 - ap[11 + q] * k1;
+    }
   }
   __syncthreads();
   if (t < np) {
@@ -1025,7 +1039,7 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
     {
     ProfScope ps(KID_POINT, st);
     hipLaunchKernelGGL(k_point, dim3(p->n_groups), dim3(256), 0, st, p->d_grp_pt, p->d_pt_ptr, p->d_perm,
-                       p->d_tp_ptr, p->d_pair_entry, B, xt, xp, w, mu, fold_u, Vinv, eps_b, g, T);
+                       p->d_tp_ptr, p->d_pair_entry, A, B, xt, xp, w, mu, fold_u, Vinv, eps_b, g, T);
   }
     int rc = check_launch("k_point");
     if (rc) return rc;

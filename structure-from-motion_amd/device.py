@@ -233,11 +233,13 @@ class DeviceProblem:
         _lib.check(self.lib.sfm_ba_camera_prepare(p(self.R), p(self.C), p(self.K), self.k_stride, self.m,
                                                   p(self.cam_blk), p(self.flags), _stream()))
 
-    def jacobian(self, want_pred=True):
+    def jacobian(self, want_pred=True, want_B=True):
+        """``want_B=False``: B is not written; assemble / back_substitute called with ``B=False``
+        take it from A (dF/dX = -dF/dC)."""
         p = _lib.ptr
         _lib.check(self.lib.sfm_ba_jacobian(p(self.cam_blk), p(self.P), p(self.X), p(self.cam_idx), p(self.pt_idx),
-                                            self.N, p(self.A), p(self.B), p(self.x_pred) if want_pred else None,
-                                            _stream()))
+                                            self.N, p(self.A), p(self.B) if want_B else None,
+                                            p(self.x_pred) if want_pred else None, _stream()))
 
     def predict(self):
         p = _lib.ptr
@@ -268,7 +270,7 @@ class DeviceProblem:
             # (row n7, the right-hand side, included: a shard need not observe every camera)
             self.sys[: (n7 + 1) * n7].zero_()
         _lib.check(self.lib.sfm_ba_schur_assemble(
-            self.plan.handle, p(self.A if A is None else A), p(self.B if B is None else B),
+            self.plan.handle, p(self.A if A is None else A), None if B is False else p(self.B if B is None else B),
             p(self.x_true if x_true is None else x_true), p(self.x_pred if x_pred is None else x_pred),
             p(weights), float(mu), float(mu_u), p(self.S), p(self.e), p(self.U) if by_products else None,
             p(self.eps_a) if by_products else None,
@@ -299,8 +301,8 @@ class DeviceProblem:
     def back_substitute(self, weights=None, update_points=False, A=None, B=None):
         p = _lib.ptr
         _lib.check(self.lib.sfm_ba_back_substitute(
-            self.plan.handle, p(self.A if A is None else A), p(self.B if B is None else B), p(weights),
-            p(self.V_inv), p(self.eps_b), p(self.delta_a), p(self.delta_b),
+            self.plan.handle, p(self.A if A is None else A), None if B is False else p(self.B if B is None else B),
+            p(weights), p(self.V_inv), p(self.eps_b), p(self.delta_a), p(self.delta_b),
             p(self.X) if update_points else None, float(self.X_STEP), _stream()))
 
     def update_cameras(self):
@@ -329,10 +331,10 @@ class DeviceProblem:
     def iterate_async(self, mu=None):
         mu = self.MU if mu is None else mu
         self.camera_prepare()
-        self.jacobian()
-        self.assemble(mu, by_products=False, reduce_packed=True)
+        self.jacobian(want_B=False)
+        self.assemble(mu, by_products=False, reduce_packed=True, B=False)
         self.solve()
-        self.back_substitute(update_points=True)
+        self.back_substitute(update_points=True, B=False)
         self.update_cameras()
         self.cost_async()
 
