@@ -360,3 +360,24 @@ def test_maximum_views_and_ragged_shapes(ba):
     pt2 = np.concatenate([np.zeros(257), np.ones(257)]).astype(np.int32)
     with pytest.raises(_lib.SfmBaError):
         ba.dev.Plan(cam2, pt2)
+
+
+def test_point_block_taken_from_A(ba):
+    """With no B handed over, assembly and back-substitution use minus the camera-centre block of A
+    (dF/dX = -dF/dC, /root/reference/src/jacobian.py:29-49): bit-identical to the run with B."""
+    from sfm_amd import synthetic
+    from sfm_amd.device import DeviceProblem
+
+    p = synthetic.make_problem(12, 2500, k=5, seed=4)
+    prob = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true)
+    prob.camera_prepare()
+    prob.jacobian()
+    outs = []
+    for B in (None, False):
+        prob.sys.zero_()
+        prob.assemble(0.5, B=B)
+        prob.solve()
+        prob.back_substitute(B=B)
+        outs.append([t.clone() for t in (prob.V_inv, prob.eps_b, prob.e, prob.delta_a, prob.delta_b)])
+    for a, b in zip(*outs):
+        assert bool((a == b).all().item())
