@@ -51,6 +51,8 @@ if d is not None:
         out.append("* %s: %.1f us, algorithmic %.1f MB (%.0f GB/s)%s" % (
             gname, 1e3 * g["ms"], g["bytes"] / 1e6, g["GBps"],
             ", measured traffic %.1f MB (%.0f GB/s)" % (g["traffic"] / 1e6, g["traffic_GBps"]) if g.get("traffic") else ""))
+    if r.get("note"):
+        out.append("* note: " + r["note"])
     cb = d.get("cpu_baseline")
     if cb:
         out += ["* CPU baseline (`kind: %s`, %d BLAS threads): %.3g observations/s — %s" % (
