@@ -145,7 +145,9 @@ int sfm_ba_jacobian(const double* d_cam_blk, const double* d_P, const double* d_
  * Outputs:
  *   d_S   [(7m+1), 7m] row-major: rows 0..7m-1 = S (both triangles; blocks of camera pairs
  *         without a shared point are left untouched - zero the buffer once before the first call),
- *         row 7m = e flattened
+ *         row 7m = e flattened.  With d_U, d_eps_a and d_cam_red all NULL (a caller that only
+ *         wants the solve) the blocks above the diagonal are not written: the solvers read the
+ *         lower triangle only
  *   d_e [m,7], d_U [m,7,7], d_eps_a [m,7]      (d_U, d_eps_a may be NULL)
  *   d_V_inv [n,3,3], d_eps_b [n,3]
  *   d_cam_red [m, SFM_BA_CAM_RED] per-camera sums without damping (may be NULL): what a sharded

@@ -722,7 +722,9 @@ __global__ __launch_bounds__(64) void k_pair_blocks(
         if (r == c) u += mu_u;
         S[(7 * (int64_t)j + r) * ld + 7 * k + c] = u - av;
       } else {
-        S[(7 * (int64_t)j + r) * ld + 7 * k + c] = -av;
+        // (the solvers read the lower triangle only: a caller that wants nothing but the solve gets
+        // no mirror image)
+        if (!fold_u) S[(7 * (int64_t)j + r) * ld + 7 * k + c] = -av;
         S[(7 * (int64_t)k + c) * ld + 7 * j + r] = -av;
       }
     }
@@ -761,7 +763,7 @@ __global__ __launch_bounds__(64) void k_pair_finish(
     if (r == c) u += mu_u;
     S[(7 * (int64_t)j + r) * ld + 7 * k + c] = u - a;
   } else {
-    S[(7 * (int64_t)j + r) * ld + 7 * k + c] = -a;
+    if (!fold_u) S[(7 * (int64_t)j + r) * ld + 7 * k + c] = -a;
     S[(7 * (int64_t)k + c) * ld + 7 * j + r] = -a;
   }
 }
