@@ -294,8 +294,14 @@ int sfm_ba_pnp_inliers(const double* d_x, const double* d_X, const double* d_K, 
  * the launch stream; sfm_ba_profile_read waits for them, adds the elapsed milliseconds and launch
  * counts per kernel id into the two arrays of sfm_ba_profile_kernel_count() entries and forgets
  * them.  "solve_reduced" is one id for the whole factor-and-solve sequence.
+ *   sfm_ba_profile_enable(mode): 0 off; 1 on; 2 on, and a timed launch that directly follows another
+ *   timed launch on the same stream starts at that launch's stop event instead of recording one of
+ *   its own (half the event records; the caller asserts that it enqueues nothing else on the stream
+ *   between the library's calls - anything it did enqueue would be counted into the next launch).
+ *   sfm_ba_profile_select(mask): bit i set = kernel id i is timed (default: all).
  * ---------------------------------------------------------------------------------------- */
-int sfm_ba_profile_enable(int on);
+int sfm_ba_profile_enable(int mode);
+int sfm_ba_profile_select(uint64_t kernel_mask);
 int sfm_ba_profile_kernel_count(void);
 const char* sfm_ba_profile_kernel_name(int id);
 int sfm_ba_profile_read(double* ms_total, int64_t* launches);

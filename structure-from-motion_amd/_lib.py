@@ -53,6 +53,7 @@ SYMBOLS = {
     "sfm_ba_cost_partial": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_ba_cost_finish": (_int, [_vp, _i32, _vp, _vp]),
     "sfm_ba_profile_enable": (_int, [_int]),
+    "sfm_ba_profile_select": (_int, [C.c_uint64]),
     "sfm_ba_profile_kernel_count": (_int, []),
     "sfm_ba_profile_kernel_name": (C.c_char_p, [_int]),
     "sfm_ba_profile_read": (_int, [C.POINTER(_f64), C.POINTER(_i64)]),
@@ -111,8 +112,19 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def profile_enable(on: bool):
-    check(load().sfm_ba_profile_enable(int(bool(on))))
+def profile_enable(on, chained=False, kernels=None):
+    """Per-kernel HIP-event timing on/off.  ``chained``: consecutive timed launches share an event
+    (only valid when nothing else is enqueued on the stream between the library's calls).
+    ``kernels``: names of the kernels to time (default: all)."""
+    lib = load()
+    mask = (1 << 64) - 1
+    if kernels is not None:
+        names = [lib.sfm_ba_profile_kernel_name(i).decode() for i in range(lib.sfm_ba_profile_kernel_count())]
+        mask = 0
+        for k in kernels:
+            mask |= 1 << names.index(k)
+    check(lib.sfm_ba_profile_select(mask))
+    check(lib.sfm_ba_profile_enable((2 if chained else 1) if on else 0))
 
 
 def profile_read():

@@ -93,6 +93,7 @@ class ProfScope {
   int id_;
   hipStream_t st_;
   void* start_;
+  bool shared_ = false;
 };
 
 #define SFMBA_HIP(call)                         \

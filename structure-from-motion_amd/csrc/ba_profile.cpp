@@ -14,9 +14,15 @@ static const char* kNames[KID_COUNT] = {
 struct Pending {
   int id;
   hipEvent_t start, stop;
+  bool start_shared;  // start is the stop event of the scope before (chained mode)
 };
 
 static bool g_enabled = false;
+static bool g_chained = false;        // a scope that follows another one directly starts at its stop event
+static uint64_t g_mask = ~uint64_t(0);  // kernel ids that are timed
+static hipEvent_t g_chain_event = nullptr;
+static hipStream_t g_chain_stream = nullptr;
+static bool g_chain_valid = false;
 static std::mutex g_mu;
 static std::vector<Pending> g_pending;
 static std::vector<hipEvent_t> g_pool;
@@ -37,6 +43,15 @@ static hipEvent_t get_event() {
 ProfScope::ProfScope(int id, hipStream_t st) : id_(id), st_(st), start_(nullptr) {
   if (!g_enabled) return;
   std::lock_guard<std::mutex> lk(g_mu);
+  if (!((g_mask >> id) & 1)) {
+    g_chain_valid = false;  // an untimed launch follows: the next timed scope needs its own start
+    return;
+  }
+  if (g_chained && g_chain_valid && g_chain_stream == st_) {
+    start_ = g_chain_event;
+    shared_ = true;
+    return;
+  }
   start_ = get_event();
   if (start_) (void)hipEventRecord(static_cast<hipEvent_t>(start_), st_);
 }
@@ -47,16 +62,28 @@ ProfScope::~ProfScope() {
   hipEvent_t stop = get_event();
   if (!stop) return;
   (void)hipEventRecord(stop, st_);
-  g_pending.push_back(Pending{id_, static_cast<hipEvent_t>(start_), stop});
+  g_pending.push_back(Pending{id_, static_cast<hipEvent_t>(start_), stop, shared_});
+  g_chain_event = stop;
+  g_chain_stream = st_;
+  g_chain_valid = true;
 }
 
 }  // namespace sfmba
 
 using namespace sfmba;
 
-extern "C" int sfm_ba_profile_enable(int on) {
+extern "C" int sfm_ba_profile_enable(int mode) {
   std::lock_guard<std::mutex> lk(g_mu);
-  g_enabled = on != 0;
+  g_enabled = mode != 0;
+  g_chained = mode == 2;
+  g_chain_valid = false;
+  return SFM_BA_OK;
+}
+
+extern "C" int sfm_ba_profile_select(uint64_t kernel_mask) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_mask = kernel_mask;
+  g_chain_valid = false;
   return SFM_BA_OK;
 }
 
@@ -77,9 +104,10 @@ extern "C" int sfm_ba_profile_read(double* ms_total, int64_t* launches) {
     SFMBA_HIP(hipEventElapsedTime(&ms, p.start, p.stop));
     ms_total[p.id] += ms;
     launches[p.id] += 1;
-    g_pool.push_back(p.start);
+    if (!p.start_shared) g_pool.push_back(p.start);
     g_pool.push_back(p.stop);
   }
   g_pending.clear();
+  g_chain_valid = false;
   return SFM_BA_OK;
 }
