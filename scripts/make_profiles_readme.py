@@ -64,7 +64,7 @@ summ = os.path.join(P, f"{tag}_c4_banded_kernel_summary.txt")
 if os.path.exists(summ):
     out += ["", f"## rocprofv3 `--kernel-trace --stats` of the default bench (`{tag}_c4_banded_kernel_stats.csv`)", "",
             "Average kernel durations agree with the HIP-event times above (the profile covers warm-up, both timed",
-            "passes of `bench.py`: 23 iterations).", "", "```"]
+            "passes of `bench.py` and the pass that times the small kernels: 33 iterations).", "", "```"]
     out += [line.rstrip()[:150] for line in open(summ)]
     out += ["```"]
 pmc = os.path.join(P, f"{tag}_pmc_traffic.json")
