@@ -381,3 +381,39 @@ def test_point_block_taken_from_A(ba):
         outs.append([t.clone() for t in (prob.V_inv, prob.eps_b, prob.e, prob.delta_a, prob.delta_b)])
     for a, b in zip(*outs):
         assert bool((a == b).all().item())
+
+
+def test_profile_selection_and_chained_events(ba):
+    """Timing a subset of the kernels, with and without shared events between consecutive launches:
+    only the selected kernels are reported, once per launch, and both modes see the same durations
+    to within the gaps between launches."""
+    import torch
+
+    from sfm_amd import _lib, synthetic
+    from sfm_amd.device import DeviceProblem
+
+    p = synthetic.make_problem(40, 60000, k=6, seed=2)
+    prob = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true)
+    for _ in range(2):
+        prob.iterate_async()
+    torch.cuda.synchronize()
+    _lib.profile_read()
+    sel = ["k_jacobian", "k_point", "k_pair_blocks", "k_back_substitute"]
+    res = {}
+    try:
+        for chained in (False, True):
+            _lib.profile_enable(True, chained=chained, kernels=sel)
+            for _ in range(5):
+                prob.iterate_async()
+            torch.cuda.synchronize()
+            _lib.profile_enable(False)
+            res[chained] = _lib.profile_read()
+    finally:
+        _lib.profile_enable(False)
+        _lib.profile_read()
+    for chained in (False, True):
+        assert sorted(res[chained]) == sorted(sel)
+        assert all(cnt == 5 and ms > 0 for ms, cnt in res[chained].values())
+    for k in sel:
+        a, b = res[False][k][0], res[True][k][0]
+        assert abs(a - b) <= 0.5 * max(a, b) + 0.05, (k, a, b)
