@@ -235,6 +235,12 @@ int sfm_ba_back_substitute(const sfm_ba_plan* plan, const double* d_A, const dou
 int sfm_ba_update_cameras(double* d_R, double* d_T, double* d_C, double* d_P, const double* d_K,
                           int k_stride, const double* d_delta_a, int32_t m, int32_t first_cam,
                           double q_step, double c_step, int32_t* d_flags, void* stream);
+/* The same, and the prepared record of every camera in its new state (d_cam_blk, d_blk_flags as
+ * sfm_ba_camera_prepare writes them): the next iteration then starts at sfm_ba_jacobian. */
+int sfm_ba_update_cameras_prepare(double* d_R, double* d_T, double* d_C, double* d_P, const double* d_K,
+                                  int k_stride, const double* d_delta_a, int32_t m, int32_t first_cam,
+                                  double q_step, double c_step, int32_t* d_flags, double* d_cam_blk,
+                                  int32_t* d_blk_flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Cost.  Work of `compute_reprojection_error_total` (src/bundle_adjustment.py:9-19): per camera
@@ -246,6 +252,11 @@ int sfm_ba_cost_partial(const sfm_ba_plan* plan, const double* d_P, const double
                         const int32_t* d_cam_idx, const int32_t* d_pt_idx, const double* d_x_true,
                         double* d_cam_ssq, void* d_workspace, void* stream);
 int sfm_ba_cost_finish(const double* d_cam_ssq, int32_t m, double* d_cost, void* stream);
+/* Both steps in two launches instead of three, for a run that has nothing to all-reduce in between:
+ * d_cam_ssq [m] and d_cost[0] as above, bit for bit. */
+int sfm_ba_cost(const sfm_ba_plan* plan, const double* d_P, const double* d_X, const int32_t* d_cam_idx,
+                const int32_t* d_pt_idx, const double* d_x_true, double* d_cam_ssq, double* d_cost,
+                void* d_workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Two-view linear triangulation: the step that produces the points bundle adjustment starts from.

@@ -51,6 +51,9 @@ SYMBOLS = {
     "sfm_ba_back_substitute": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp]),
     "sfm_ba_update_cameras": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _i32, _i32, _f64, _f64, _vp, _vp]),
     "sfm_ba_cost_partial": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sfm_ba_update_cameras_prepare": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _i32, _i32, _f64, _f64, _vp, _vp, _vp,
+                                             _vp]),
+    "sfm_ba_cost": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_ba_cost_finish": (_int, [_vp, _i32, _vp, _vp]),
     "sfm_ba_profile_enable": (_int, [_int]),
     "sfm_ba_profile_select": (_int, [C.c_uint64]),

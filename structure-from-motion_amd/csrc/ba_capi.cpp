@@ -132,7 +132,26 @@ int sfm_ba_update_cameras(double* d_R, double* d_T, double* d_C, double* d_P, co
   if (!d_R || !d_T || !d_C || !d_K || !d_delta_a || m < 0 || first_cam < 0 || (k_stride != 0 && k_stride != 9))
     return SFM_BA_EINVAL;
   return launch_update_cameras(d_R, d_T, d_C, d_P, d_K, k_stride, d_delta_a, m, first_cam, q_step, c_step, d_flags,
-                               static_cast<hipStream_t>(stream));
+                               nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int sfm_ba_update_cameras_prepare(double* d_R, double* d_T, double* d_C, double* d_P, const double* d_K, int k_stride,
+                                  const double* d_delta_a, int32_t m, int32_t first_cam, double q_step, double c_step,
+                                  int32_t* d_flags, double* d_cam_blk, int32_t* d_blk_flags, void* stream) {
+  if (!d_R || !d_T || !d_C || !d_K || !d_delta_a || !d_cam_blk || m < 0 || first_cam < 0 ||
+      (k_stride != 0 && k_stride != 9))
+    return SFM_BA_EINVAL;
+  return launch_update_cameras(d_R, d_T, d_C, d_P, d_K, k_stride, d_delta_a, m, first_cam, q_step, c_step, d_flags,
+                               d_cam_blk, d_blk_flags, static_cast<hipStream_t>(stream));
+}
+
+int sfm_ba_cost(const sfm_ba_plan* plan, const double* d_P, const double* d_X, const int32_t* d_cam_idx,
+                const int32_t* d_pt_idx, const double* d_x_true, double* d_cam_ssq, double* d_cost, void* d_workspace,
+                void* stream) {
+  if (!plan || !d_P || !d_X || !d_cam_idx || !d_pt_idx || !d_x_true || !d_cam_ssq || !d_cost || !d_workspace)
+    return SFM_BA_EINVAL;
+  return launch_cost(plan, d_P, d_X, d_cam_idx, d_pt_idx, d_x_true, d_cam_ssq, d_cost, d_workspace,
+                     static_cast<hipStream_t>(stream));
 }
 
 int sfm_ba_cost_partial(const sfm_ba_plan* plan, const double* d_P, const double* d_X, const int32_t* d_cam_idx,

@@ -71,24 +71,16 @@ __device__ __forceinline__ double det3(const double* R) {
 // ------------------------------------------------------------------------------------------
 // per-camera record
 // ------------------------------------------------------------------------------------------
-__global__ void k_camera_prepare(const double* __restrict__ R, const double* __restrict__ C,
-                                 const double* __restrict__ K, int k_stride, int m,
-                                 double* __restrict__ blk, int32_t* __restrict__ flags) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= m) return;
-  const double* r = R + 9 * (int64_t)j;
-  const double* k = K + (int64_t)k_stride * j;
-  double* o = blk + (int64_t)SFM_BA_CAM_BLK * j;
+// prepared record of one camera (layout: see sfm_ba_camera_prepare) from its rotation rr, centre c and
+// intrinsics k; returns the flag bits of the camera
+__device__ __forceinline__ int camera_record(const double* rr, const double* c, const double* k, double* o) {
   const double fx = k[0], fy = k[4], ox = k[2], oy = k[5];
-  double rr[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) rr[i] = r[i];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     o[i] = fx * rr[i] + ox * rr[6 + i];
     o[3 + i] = fy * rr[3 + i] + oy * rr[6 + i];
     o[6 + i] = rr[6 + i];
-    o[9 + i] = C[3 * (int64_t)j + i];
+    o[9 + i] = c[i];
   }
   double q[4];
   rot_to_quat(rr, q);
@@ -117,6 +109,20 @@ __global__ void k_camera_prepare(const double* __restrict__ R, const double* __r
 #pragma unroll
   for (int i = 0; i < 12; ++i) chk += o[i];
   if (!isfinite(chk)) f |= SFM_BA_FLAG_NONFINITE;
+  return f;
+}
+
+__global__ void k_camera_prepare(const double* __restrict__ R, const double* __restrict__ C,
+                                 const double* __restrict__ K, int k_stride, int m,
+                                 double* __restrict__ blk, int32_t* __restrict__ flags) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  double rr[9], cc[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) rr[i] = R[9 * (int64_t)j + i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) cc[i] = C[3 * (int64_t)j + i];
+  const int f = camera_record(rr, cc, K + (int64_t)k_stride * j, blk + (int64_t)SFM_BA_CAM_BLK * j);
   if (flags) flags[j] = f;
 }
 
@@ -888,12 +894,25 @@ __global__ __launch_bounds__(256) void k_back_substitute(
 __global__ void k_update_cameras(double* __restrict__ R, double* __restrict__ T, double* __restrict__ C,
                                  double* __restrict__ P, const double* __restrict__ K, int k_stride,
                                  const double* __restrict__ da, int m, int first, double q_step,
-                                 double c_step, int32_t* __restrict__ flags) {
+                                 double c_step, int32_t* __restrict__ flags, double* __restrict__ blk,
+                                 int32_t* __restrict__ blk_flags) {
+  // blk (may be null): the prepared record of every camera in its new state, what k_camera_prepare
+  // would compute next - the following iteration then needs no launch for it
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= m || j < first) return;
+  if (j >= m) return;
   double r[9], q[4];
 #pragma unroll
   for (int i = 0; i < 9; ++i) r[i] = R[9 * (int64_t)j + i];
+  if (j < first) {
+    if (blk) {
+      double cc[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) cc[i] = C[3 * (int64_t)j + i];
+      const int pf = camera_record(r, cc, K + (int64_t)k_stride * j, blk + (int64_t)SFM_BA_CAM_BLK * j);
+      if (blk_flags) blk_flags[j] = pf;
+    }
+    return;
+  }
   int f = 0;
   if (!(fabs(det3(r) - 1.0) <= 1e-8 + 1e-5)) f |= SFM_BA_FLAG_DET_NOT_ONE;
   rot_to_quat(r, q);
@@ -933,6 +952,10 @@ __global__ void k_update_cameras(double* __restrict__ R, double* __restrict__ T,
     }
   }
   if (flags) flags[j] = f;
+  if (blk) {
+    const int pf = camera_record(r, c, k, blk + (int64_t)SFM_BA_CAM_BLK * j);
+    if (blk_flags) blk_flags[j] = pf;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1120,12 +1143,12 @@ int launch_back_substitute(const sfm_ba_plan* p, const double* A, const double* 
 
 int launch_update_cameras(double* R, double* T, double* C, double* P, const double* K, int k_stride,
                           const double* da, int m, int first, double q_step, double c_step,
-                          int32_t* flags, hipStream_t st) {
+                          int32_t* flags, double* blk, int32_t* blk_flags, hipStream_t st) {
   if (m <= 0) return SFM_BA_OK;
   {
     ProfScope ps(KID_UPDATE, st);
     hipLaunchKernelGGL(k_update_cameras, dim3((m + 63) / 64), dim3(64), 0, st, R, T, C, P, K, k_stride, da, m,
-                     first, q_step, c_step, flags);
+                     first, q_step, c_step, flags, blk, blk_flags);
   }
   return check_launch("k_update_cameras");
 }
@@ -1145,6 +1168,47 @@ int launch_cost_partial(const sfm_ba_plan* p, const double* P, const double* X, 
   hipLaunchKernelGGL(k_cost_camera_sum, dim3((p->m + 255) / 256), dim3(256), 0, st, p->d_cam_item_ptr, campart,
                      p->m, ssq);
   return check_launch("k_cost_camera_sum");
+}
+
+// single rank: per-camera sums and the cost in one launch (same order of additions as the two kernels)
+__global__ __launch_bounds__(256) void k_cost_sum_finish(const int32_t* __restrict__ cam_item_ptr,
+                                                         const double* __restrict__ part, int m,
+                                                         double* __restrict__ ssq, double* __restrict__ cost) {
+  __shared__ double red[256];
+  const int t = threadIdx.x;
+  double a = 0.0;
+  for (int j = t; j < m; j += 256) {
+    double sj = 0.0;
+    for (int it = cam_item_ptr[j]; it < cam_item_ptr[j + 1]; ++it) sj += part[it];
+    ssq[j] = sj;
+    a += sqrt(sj);
+  }
+  red[t] = a;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) red[t] += red[t + s];
+    __syncthreads();
+  }
+  if (t == 0) cost[0] = red[0] / (double)m;
+}
+
+int launch_cost(const sfm_ba_plan* p, const double* P, const double* X, const int32_t* cam, const int32_t* pt,
+                const double* xt, double* ssq, double* cost, void* ws, hipStream_t st) {
+  double* campart = reinterpret_cast<double*>(static_cast<char*>(ws) + p->ws_campart);
+  if (p->n_items > 0) {
+    {
+      ProfScope ps(KID_COST_ITEMS, st);
+      hipLaunchKernelGGL(k_cost_items, dim3(p->n_items), dim3(kCamThreads), 0, st, p->d_item_beg, p->d_item_end,
+                         p->d_cam_obs, P, X, cam, pt, xt, campart);
+    }
+    int rc = check_launch("k_cost_items");
+    if (rc) return rc;
+  }
+  {
+    ProfScope ps(KID_COST_FINISH, st);
+    hipLaunchKernelGGL(k_cost_sum_finish, dim3(1), dim3(256), 0, st, p->d_cam_item_ptr, campart, p->m, ssq, cost);
+  }
+  return check_launch("k_cost_sum_finish");
 }
 
 int launch_cost_finish(const double* ssq, int m, double* cost, hipStream_t st) {

@@ -193,6 +193,7 @@ class DeviceProblem:
             self.C.copy_(torch.from_numpy(np.asarray(C, dtype=np.float64).reshape(-1, 3)))
         if P is not None:
             self.P.copy_(torch.from_numpy(np.asarray(P, dtype=np.float64).reshape(-1, 12)))
+        self._blk_fresh = False
 
     def _alloc(self):
         d, m, n, N = self.device, self.m, self.n, self.N
@@ -223,6 +224,7 @@ class DeviceProblem:
         self.band_sharded = self.sharded and self.half_bandwidth <= 64
         self._packed_mu = None
         self._s_holds_foreign = False
+        self._blk_fresh = False  # cam_blk holds the records of the current R, C, K
         if self.band_sharded:
             self.packed = torch.empty((int(self.lib.sfm_ba_band_packed_elements(n7)),), dtype=F64, device=d)
         self.cost_buf = torch.zeros((1,), dtype=F64, device=d)
@@ -232,6 +234,7 @@ class DeviceProblem:
         p = _lib.ptr
         _lib.check(self.lib.sfm_ba_camera_prepare(p(self.R), p(self.C), p(self.K), self.k_stride, self.m,
                                                   p(self.cam_blk), p(self.flags), _stream()))
+        self._blk_fresh = True
 
     def jacobian(self, want_pred=True, want_B=True):
         """``want_B=False``: B is not written; assemble / back_substitute called with ``B=False``
@@ -305,15 +308,29 @@ class DeviceProblem:
             p(weights), p(self.V_inv), p(self.eps_b), p(self.delta_a), p(self.delta_b),
             p(self.X) if update_points else None, float(self.X_STEP), _stream()))
 
-    def update_cameras(self):
+    def update_cameras(self, prepare_next=False):
+        """``prepare_next``: also leave the prepared camera records of the new state in ``cam_blk``
+        (what ``camera_prepare`` would compute), so that the next iteration skips that launch."""
         p = _lib.ptr
+        if prepare_next:
+            _lib.check(self.lib.sfm_ba_update_cameras_prepare(
+                p(self.R), p(self.T), p(self.C), p(self.P), p(self.K), self.k_stride, p(self.delta_a), self.m, 1,
+                float(self.Q_STEP), float(self.C_STEP), p(self.upd_flags), p(self.cam_blk), p(self.flags), _stream()))
+            self._blk_fresh = True
+            return
         _lib.check(self.lib.sfm_ba_update_cameras(p(self.R), p(self.T), p(self.C), p(self.P), p(self.K),
                                                   self.k_stride, p(self.delta_a), self.m, 1, float(self.Q_STEP),
                                                   float(self.C_STEP), p(self.upd_flags), _stream()))
+        self._blk_fresh = False
 
     def cost_async(self):
         """Enqueue the cost of the current state into ``cost_buf`` (no synchronisation)."""
         p = _lib.ptr
+        if not self.sharded:
+            _lib.check(self.lib.sfm_ba_cost(self.plan.handle, p(self.P), p(self.X), p(self.cam_idx), p(self.pt_idx),
+                                            p(self.x_true), p(self.ssq), p(self.cost_buf), p(self.workspace),
+                                            _stream()))
+            return
         _lib.check(self.lib.sfm_ba_cost_partial(self.plan.handle, p(self.P), p(self.X), p(self.cam_idx),
                                                 p(self.pt_idx), p(self.x_true), p(self.ssq), p(self.workspace),
                                                 _stream()))
@@ -330,12 +347,13 @@ class DeviceProblem:
     # -- one Gauss-Newton iteration (src/bundle_adjustment.py:75-101) ---------------------------
     def iterate_async(self, mu=None):
         mu = self.MU if mu is None else mu
-        self.camera_prepare()
+        if not self._blk_fresh:
+            self.camera_prepare()
         self.jacobian(want_B=False)
         self.assemble(mu, by_products=False, reduce_packed=True, B=False)
         self.solve()
         self.back_substitute(update_points=True, B=False)
-        self.update_cameras()
+        self.update_cameras(prepare_next=True)
         self.cost_async()
 
     def check_flags(self):
