@@ -208,6 +208,15 @@ int sfm_ba_solve_reduced_banded(double* d_S, int32_t n7, int32_t half_bandwidth,
  * Entries of d_S outside the band are not read. */
 int64_t sfm_ba_band_packed_elements(int32_t n7);
 int sfm_ba_band_pack(const double* d_S, int32_t n7, double* d_packed, void* stream);
+/* What the ranks of a sharded run exchange when the band is narrow: per 64-row block only the lower
+ * triangle of the diagonal block, the coupling entries a half bandwidth hb <= 64 leaves non-zero
+ * (S(k1 + r, k0 + c) with c >= r + 64 - hb) and the right-hand side - about half of the packed
+ * form.  sfm_ba_band_compact fills it from S, the ranks all-reduce it, sfm_ba_band_expand turns
+ * it into the packed form sfm_ba_solve_band_packed takes. */
+int64_t sfm_ba_band_compact_elements(int32_t n7, int32_t half_bandwidth);
+int sfm_ba_band_compact(const double* d_S, int32_t n7, int32_t half_bandwidth, double* d_compact, void* stream);
+int sfm_ba_band_expand(const double* d_compact, int32_t n7, int32_t half_bandwidth, double* d_packed,
+                       void* stream);
 int sfm_ba_solve_band_packed(double* d_packed, int32_t n7, double mu_diag, double* d_delta_a,
                              void* d_chol_ws, int32_t* d_info, void* stream);
 

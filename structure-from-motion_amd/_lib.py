@@ -47,6 +47,9 @@ SYMBOLS = {
     "sfm_ba_pnp_inliers": (_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, C.c_double, _vp, _vp, _vp]),
     "sfm_ba_band_packed_elements": (_i64, [_i32]),
     "sfm_ba_band_pack": (_int, [_vp, _i32, _vp, _vp]),
+    "sfm_ba_band_compact_elements": (_i64, [_i32, _i32]),
+    "sfm_ba_band_compact": (_int, [_vp, _i32, _i32, _vp, _vp]),
+    "sfm_ba_band_expand": (_int, [_vp, _i32, _i32, _vp, _vp]),
     "sfm_ba_solve_band_packed": (_int, [_vp, _i32, _f64, _vp, _vp, _vp, _vp]),
     "sfm_ba_back_substitute": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp]),
     "sfm_ba_update_cameras": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _i32, _i32, _f64, _f64, _vp, _vp]),

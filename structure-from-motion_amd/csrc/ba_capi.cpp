@@ -111,6 +111,20 @@ int sfm_ba_band_pack(const double* d_S, int32_t n7, double* d_packed, void* stre
   return launch_band_pack(d_S, n7, d_packed, static_cast<hipStream_t>(stream));
 }
 
+int64_t sfm_ba_band_compact_elements(int32_t n7, int32_t half_bandwidth) {
+  return n7 > 0 && half_bandwidth >= 0 && half_bandwidth <= 64 ? band_compact_elements(n7, half_bandwidth) : 0;
+}
+
+int sfm_ba_band_compact(const double* d_S, int32_t n7, int32_t half_bandwidth, double* d_compact, void* stream) {
+  if (!d_S || !d_compact || n7 <= 0 || half_bandwidth < 0 || half_bandwidth > 64) return SFM_BA_EINVAL;
+  return launch_band_compact(d_S, n7, half_bandwidth, d_compact, static_cast<hipStream_t>(stream));
+}
+
+int sfm_ba_band_expand(const double* d_compact, int32_t n7, int32_t half_bandwidth, double* d_packed, void* stream) {
+  if (!d_compact || !d_packed || n7 <= 0 || half_bandwidth < 0 || half_bandwidth > 64) return SFM_BA_EINVAL;
+  return launch_band_expand(d_compact, n7, half_bandwidth, d_packed, static_cast<hipStream_t>(stream));
+}
+
 int sfm_ba_solve_band_packed(double* d_packed, int32_t n7, double mu_diag, double* d_delta_a, void* d_chol_ws,
                              int32_t* d_info, void* stream) {
   if (!d_packed || !d_delta_a || !d_chol_ws || !d_info || n7 <= 0) return SFM_BA_EINVAL;

@@ -1080,6 +1080,85 @@ int launch_band_pack(const double* S, int n, double* packed, hipStream_t st) {
   return SFM_BA_OK;
 }
 
+// Compact form of the same blocks, for the exchange between the ranks of a sharded run: per block
+// the lower triangle of D_i (2080), the entries of the coupling that a half bandwidth hb leaves
+// non-zero - S(k1 + r, k0 + c) with c >= r + 64 - hb - and e_i (64).
+__host__ __device__ inline int compact_b_row_start(int r, int off) {
+  // entries of rows 0 .. r-1: sum of max(0, 64 - off - r')
+  const int w = NB - off;  // length of row 0
+  const int full = r < w ? r : w;
+  return full * w - full * (full - 1) / 2;
+}
+
+int64_t band_compact_elements(int n, int half_bandwidth) {
+  const int64_t np = (n + NB - 1) / NB;
+  const int off = NB - half_bandwidth < 0 ? 0 : NB - half_bandwidth;
+  return np * (NB * (NB + 1) / 2 + compact_b_row_start(NB, off) + NB);
+}
+
+// one workgroup per block: S -> compact (to_compact != 0), or compact -> [D | B | e] with zero fill
+__global__ __launch_bounds__(256) void k_bcr_compact(const double* __restrict__ S, int n, int np, int off,
+                                                     double* __restrict__ compact, double* __restrict__ Dk,
+                                                     double* __restrict__ Bk, double* __restrict__ ek, int to_compact) {
+  const int i = blockIdx.x, t = threadIdx.x;
+  const int k0 = i * NB, k1 = k0 + NB;
+  const int nb = (n - k0) < NB ? (n - k0) : NB;
+  const int nb1 = (n - k1) < NB ? (n - k1) : NB;  // <= 0 for the last block
+  const int nd = NB * (NB + 1) / 2, nbz = compact_b_row_start(NB, off);
+  double* cb = compact + (int64_t)i * (nd + nbz + NB);
+  for (int idx = t; idx < NB * NB; idx += 256) {
+    const int r = idx / NB, c = idx % NB;
+    const bool in_d = c <= r, in_b = c >= r + off;
+    const int pd = r * (r + 1) / 2 + c;
+    const int pb = nd + compact_b_row_start(r, off) + (c - r - off);
+    if (to_compact) {
+      if (in_d) {
+        double v = (r == c) ? 1.0 : 0.0;  // identity past the matrix edge
+        if (r < nb && c < nb) v = S[(int64_t)(k0 + r) * n + k0 + c];
+        cb[pd] = v;
+      }
+      if (in_b) cb[pb] = (r < nb1) ? S[(int64_t)(k1 + r) * n + k0 + c] : 0.0;
+    } else {
+      Dk[(int64_t)i * NB * NB + idx] = in_d ? cb[pd] : 0.0;
+      Bk[(int64_t)i * NB * NB + idx] = in_b ? cb[pb] : 0.0;
+    }
+  }
+  if (t < NB) {
+    if (to_compact)
+      cb[nd + nbz + t] = t < nb ? S[(int64_t)n * n + k0 + t] : 0.0;
+    else
+      ek[k0 + t] = cb[nd + nbz + t];
+  }
+}
+
+int launch_band_compact(const double* S, int n, int half_bandwidth, double* compact, hipStream_t st) {
+  const int np = (n + NB - 1) / NB;
+  const int off = NB - half_bandwidth < 0 ? 0 : NB - half_bandwidth;
+  hipLaunchKernelGGL(k_bcr_compact, dim3(np), dim3(256), 0, st, S, n, np, off, compact, nullptr, nullptr, nullptr, 1);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_hip_error(err, "k_bcr_compact launch");
+    return SFM_BA_EHIP;
+  }
+  return SFM_BA_OK;
+}
+
+int launch_band_expand(const double* compact, int n, int half_bandwidth, double* packed, hipStream_t st) {
+  const int np = (n + NB - 1) / NB;
+  const int off = NB - half_bandwidth < 0 ? 0 : NB - half_bandwidth;
+  double* Dk = packed;
+  double* Bk = Dk + (int64_t)np * NB * NB;
+  double* ek = Bk + (int64_t)np * NB * NB;
+  hipLaunchKernelGGL(k_bcr_compact, dim3(np), dim3(256), 0, st, nullptr, n, np, off, const_cast<double*>(compact), Dk, Bk,
+                     ek, 0);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_hip_error(err, "k_bcr_compact launch");
+    return SFM_BA_EHIP;
+  }
+  return SFM_BA_OK;
+}
+
 // damping added after a sharded run's all-reduce: the diagonal of S lives in the diagonal blocks
 __global__ void k_bcr_add_diagonal(double* __restrict__ Dk, int n, double mu) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -134,6 +134,9 @@ int launch_solve_reduced(double* S, int n7, int half_bandwidth, double* da, void
 
 int64_t band_packed_elements(int n7);
 int launch_band_pack(const double* S, int n7, double* packed, hipStream_t st);
+int64_t band_compact_elements(int n7, int half_bandwidth);
+int launch_band_compact(const double* S, int n7, int half_bandwidth, double* compact, hipStream_t st);
+int launch_band_expand(const double* compact, int n7, int half_bandwidth, double* packed, hipStream_t st);
 int launch_solve_band_packed(double* packed, int n7, double mu_diag, double* da, void* ws, int32_t* info,
                              hipStream_t st);
 

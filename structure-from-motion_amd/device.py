@@ -227,6 +227,8 @@ class DeviceProblem:
         self._blk_fresh = False  # cam_blk holds the records of the current R, C, K
         if self.band_sharded:
             self.packed = torch.empty((int(self.lib.sfm_ba_band_packed_elements(n7)),), dtype=F64, device=d)
+            self.compact = torch.empty((int(self.lib.sfm_ba_band_compact_elements(n7, self.half_bandwidth)),),
+                                       dtype=F64, device=d)
         self.cost_buf = torch.zeros((1,), dtype=F64, device=d)
 
     # -- single stages ---------------------------------------------------------------------
@@ -282,8 +284,10 @@ class DeviceProblem:
             import torch.distributed as dist
 
             # blocks and right-hand-side entries this rank never writes stay zero from allocation
-            _lib.check(self.lib.sfm_ba_band_pack(p(self.S), n7, p(self.packed), _stream()))
-            self._all_reduce(self.packed)
+            # (only the entries a band of this width can hold travel: about half of the packed form)
+            _lib.check(self.lib.sfm_ba_band_compact(p(self.S), n7, self.half_bandwidth, p(self.compact), _stream()))
+            self._all_reduce(self.compact)
+            _lib.check(self.lib.sfm_ba_band_expand(p(self.compact), n7, self.half_bandwidth, p(self.packed), _stream()))
         elif self.sharded:
             import torch.distributed as dist
 

@@ -43,10 +43,11 @@ def local_problem(problem: BAProblem, rank: int, world: int) -> tuple[BAProblem,
 def packed_system_elements(m: int, half_bandwidth: int | None = None) -> int:
     """fp64 elements of the per-iteration all-reduces: the camera system and the per-camera cost sums
     (m).  Dense system: S (7m x 7m) and e (7m).  With a half bandwidth of at most 64 the ranks exchange
-    the block-tridiagonal form: per 64-row block a 64 x 64 diagonal block, a 64 x 64 coupling, 64
-    right-hand-side entries."""
+    the block-tridiagonal form: per 64-row block the lower triangle of the 64 x 64 diagonal block,
+    the entries of the 64 x 64 coupling that the band leaves non-zero, 64 right-hand-side entries."""
     n7 = 7 * m
     if half_bandwidth is not None and half_bandwidth <= 64:
         np_ = (n7 + 63) // 64
-        return np_ * (2 * 64 * 64 + 64) + m
+        w = half_bandwidth  # 64 - (64 - hb): coupling entries S(k1 + r, k0 + c) with c >= r + 64 - hb
+        return np_ * (64 * 65 // 2 + w * (w + 1) // 2 + 64) + m
     return (n7 + 1) * n7 + m
