@@ -42,7 +42,8 @@ def algorithmic_bytes(N, n, m, s_blocks):
 # kernels only run when a caller asks for U / eps_a)
 GROUPS = {
     "jacobian": ["k_jacobian"],
-    "assembly": ["k_point", "k_camera_items", "k_camera_finish", "k_pair_blocks", "k_pair_finish"],
+    "assembly": ["k_fused_runs", "k_fused_reduce", "k_fused_finish", "k_point", "k_camera_items", "k_camera_finish",
+                 "k_pair_blocks", "k_pair_finish"],
     "back_substitution": ["k_back_substitute"],
 }
 

@@ -87,7 +87,9 @@ void sfm_ba_plan_destroy(sfm_ba_plan* plan);
  * 2 slot_cam, 3 tp_ptr, 4 pair_entry, 5 grp_pt, 6 cam_obs (empty when the caller order is
  * camera-sorted), 7-9 per-camera items (camera, begin, end), 10 cam_item_ptr, 11-12 block cameras
  * (j, k), 13 pair entries (two uint32 each), 14-17 pair items (block, begin, end, partial), 18-20
- * split blocks (block, first partial, partials).  *bytes receives the array's size; h_dst may be
+ * split blocks (block, first partial, partials), 21-25 runs of the fused assembly (first point of
+ * each run, base camera, observation per (point, window slot), runs grouped by window: row pointer
+ * and run ids; all empty when the plan has no runs).  *bytes receives the array's size; h_dst may be
  * null to query it, otherwise `capacity` must be at least that size. */
 int sfm_ba_plan_read(const sfm_ba_plan* plan, int field, void* h_dst, int64_t capacity, int64_t* bytes);
 /* sizes: what[0]=n_cams, [1]=n_pts, [2]=n_obs, [3]=number of camera-pair blocks (j<=k) with a shared
@@ -99,6 +101,18 @@ int sfm_ba_plan_sizes(const sfm_ba_plan* plan, int64_t what[8]);
  * point).  `Indices.shared_point_indices` (src/sparse_ba.py:107-128) is where the reference finds
  * the same empty blocks, one pair at a time.  A sharded run takes the maximum over its ranks. */
 int32_t sfm_ba_plan_half_bandwidth(const sfm_ba_plan* plan);
+/* Runs of the fused assembly.  When every point's cameras lie within 8 consecutive camera ids (what
+ * an incremental reconstruction produces: `Map.update_map`, src/map.py:17-37, appends points as
+ * frames are registered) the plan also groups consecutive points into runs that share a window of
+ * 6 or 8 cameras, and sfm_ba_schur_assemble - called without d_B, weights, d_U, d_eps_a and
+ * d_cam_red, with mu > 0 - then forms V^-1, eps_b, S and e in a single pass over d_A.
+ *   info[0] = 1 when that path will be taken, [1] = cameras per window (0: pattern not eligible),
+ *   [2] = first-cameras that share a window, [3] = largest run length in points, [4] = runs,
+ *   [5] = windows.  sfm_ba_plan_set_fused(plan, 0) turns the path off for this plan (tests compare
+ *   the two paths); both give the same S and e to rounding.  No counterpart in the reference, whose
+ *   calc_S (src/sparse_ba.py:237-258) walks camera pairs. */
+int sfm_ba_plan_fused_info(const sfm_ba_plan* plan, int32_t info[6]);
+int sfm_ba_plan_set_fused(sfm_ba_plan* plan, int enable);
 /* bytes of the scratch workspace the assemble / back-substitution entry points need */
 int64_t sfm_ba_plan_workspace_bytes(const sfm_ba_plan* plan);
 

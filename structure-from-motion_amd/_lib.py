@@ -31,6 +31,8 @@ SYMBOLS = {
     "sfm_ba_plan_read": (_int, [_vp, _int, _vp, _i64, C.POINTER(_i64)]),
     "sfm_ba_plan_sizes": (_int, [_vp, C.POINTER(_i64)]),
     "sfm_ba_plan_workspace_bytes": (_i64, [_vp]),
+    "sfm_ba_plan_fused_info": (_int, [_vp, C.POINTER(_i32)]),
+    "sfm_ba_plan_set_fused": (_int, [_vp, _int]),
     "sfm_ba_camera_prepare": (_int, [_vp, _vp, _vp, _int, _i32, _vp, _vp, _vp]),
     "sfm_ba_jacobian": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "sfm_ba_schur_assemble": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -18,6 +18,32 @@ constexpr int kPairPartStride = 56;  // doubles per partial result of a split bl
 
 // One (observation, observation) pair of a camera-pair block, as byte offsets (the kernel that walks
 // these adds a piece offset and issues the fetch; N * 112 < 2^32 is checked when the plan is built)
+// Fused point-major assembly ("runs"): a run is a range of consecutive points whose cameras all lie in
+// one window of `slots` consecutive camera ids starting at the run's base camera; lane (point, slot)
+// of a wave then owns one observation or none, 8 points per step.
+constexpr int kFzLanesPerPoint = 8;  // lanes (= slot positions of the table) per point
+constexpr int kFzSlotRec = 40;       // doubles per camera slot behind a partial's tiles: 28 (upper triangle of
+                                     // sum A^T A) + 7 (sum A^T g), padded
+struct FzShape {
+  int slots;  // camera slots of a window: 6 or 8 (3 or 4 row tiles of 16 = two cameras of 8 rows each)
+  int group;  // consecutive first-cameras that share a window: slots - span + 1
+  int pmax;   // a run is cut wherever the point id is a multiple of this
+};
+// Shape of the runs for n points whose cameras span at most span_max consecutive ids; false when the
+// fused path does not apply (a point without observations, or a span beyond 8 cameras).
+inline bool fz_shape(int32_t n, int32_t span_max, bool empty_point, FzShape* o) {
+  if (empty_point || span_max < 1 || span_max > 8) return false;
+  o->slots = span_max <= 6 ? 6 : 8;
+  o->group = o->slots - span_max + 1;
+  int pm = ((n + 2047) / 2048 + 7) & ~7;
+  o->pmax = pm < 32 ? 32 : (pm > 1024 ? 1024 : pm);
+  return true;
+}
+// runs must be long enough for their fixed cost (one partial result each) to be small
+inline bool fz_worthwhile(int32_t n, int32_t n_runs) { return (int64_t)n_runs * 24 <= (int64_t)n + 1536; }
+__host__ __device__ inline int fz_tiles(int slots) { return (slots / 2) * (slots / 2 + 1) / 2; }
+__host__ __device__ inline int64_t fz_part_stride(int slots) { return (int64_t)fz_tiles(slots) * 256 + 8 * kFzSlotRec; }
+
 struct PairEntry {
   uint32_t row_a;  // 112 * observation (caller order) of the block's row camera j: its row of A
   uint32_t row_b;  // off the diagonal (j < k): 112 * observation of camera k, same point.  On the
@@ -65,9 +91,17 @@ struct sfm_ba_plan {
   int32_t* d_mb_blk = nullptr;
   int32_t* d_mb_part = nullptr;   // first partial
   int32_t* d_mb_cnt = nullptr;    // number of partials
+  // fused point-major assembly (fz_slots = 0: the visibility pattern does not allow it)
+  int32_t fz_slots = 0, fz_group = 0, fz_pmax = 0, fz_enabled = 1;
+  int32_t n_runs = 0, n_keys = 0;
+  int32_t* d_run_pt0 = nullptr;   // [n_runs+1] first point of each run
+  int32_t* d_run_base = nullptr;  // [n_runs] first camera of the run's window
+  int32_t* d_slot_obs = nullptr;  // [n][8] observation (caller order) of point i at camera base + slot, or -1
+  int32_t* d_key_ptr = nullptr;   // [n_keys+1] runs grouped by window (key = base / group), ascending run id
+  int32_t* d_key_run = nullptr;   // [n_runs]
   int64_t device_bytes = 0;
   // workspace section offsets (bytes)
-  int64_t ws_g = 0, ws_T = 0, ws_campart = 0, ws_spart = 0, ws_total = 0;
+  int64_t ws_g = 0, ws_T = 0, ws_campart = 0, ws_spart = 0, ws_fpart = 0, ws_fkey = 0, ws_total = 0;
 };
 
 namespace sfmba {
@@ -79,7 +113,8 @@ void plan_set_workspace(sfm_ba_plan* p);  // workspace section offsets from the 
 // launch stream while profiling is enabled, and costs one branch otherwise
 enum KernelId {
   KID_CAMERA_PREPARE = 0, KID_JACOBIAN, KID_POINT, KID_CAMERA_ITEMS, KID_CAMERA_FINISH, KID_PAIR_BLOCKS,
-  KID_PAIR_FINISH, KID_SOLVE, KID_BACK, KID_UPDATE, KID_COST_ITEMS, KID_COST_FINISH, KID_CALC_W_Y, KID_TRIANGULATE, KID_COUNT
+  KID_PAIR_FINISH, KID_SOLVE, KID_BACK, KID_UPDATE, KID_COST_ITEMS, KID_COST_FINISH, KID_CALC_W_Y, KID_TRIANGULATE, KID_FUSED_RUNS,
+  KID_FUSED_REDUCE, KID_FUSED_FINISH, KID_COUNT
 };
 bool profiling_enabled();
 class ProfScope {
@@ -114,6 +149,9 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
                     const double* xp, const double* w, double mu, double mu_u, double* S, double* e,
                     double* U, double* eps_a, double* Vinv, double* eps_b, double* cam_red,
                     void* ws, hipStream_t st);
+// the fused path of launch_assemble (plan with runs, no weights, no by-products, B taken from A)
+int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* xt, const double* xp, double mu,
+                          double mu_u, double* S, double* e, double* Vinv, double* eps_b, void* ws, hipStream_t st);
 int launch_calc_W_Y(const sfm_ba_plan* p, const double* A, const double* B, const double* w,
                     const double* Vinv, const int32_t* pt, double* W, double* Y, hipStream_t st);
 int launch_add_diagonal(double* S, int n7, double mu, hipStream_t st);

@@ -1060,6 +1060,10 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
   // Callers that want none of the per-camera by-products (U, eps_a, the all-reduce records) get
   // them folded into the camera-pair kernel: no separate pass over A.
   const int fold_u = (S && !U && !eps_a && !cam_red) ? 1 : 0;
+  // ... and, where the plan found runs of points inside narrow camera windows, the whole assembly
+  // is one pass over A (ba_fused.hip).  That path takes the point block from A and needs mu > 0.
+  if (fold_u && !B && !w && mu > 0.0 && p->n_runs > 0 && p->fz_enabled)
+    return launch_assemble_fused(p, A, xt, xp, mu, mu_u, S, e, Vinv, eps_b, ws, st);
   if (p->n_groups > 0) {
     {
     ProfScope ps(KID_POINT, st);

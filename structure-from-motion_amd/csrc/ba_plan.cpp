@@ -41,6 +41,11 @@ void plan_set_workspace(sfm_ba_plan* p) {
   off = align256(off + (int64_t)std::max(p->n_items, 1) * SFM_BA_CAM_RED * (int64_t)sizeof(double));
   p->ws_spart = off;
   off = align256(off + (int64_t)std::max(p->n_parts, 1) * kPairPartStride * (int64_t)sizeof(double));
+  // fused point-major assembly: one partial result per run, one per window
+  p->ws_fpart = off;
+  off = align256(off + (int64_t)p->n_runs * fz_part_stride(p->fz_slots) * (int64_t)sizeof(double));
+  p->ws_fkey = off;
+  off = align256(off + (int64_t)p->n_keys * fz_part_stride(p->fz_slots) * (int64_t)sizeof(double));
   p->ws_total = off;
 }
 
@@ -55,7 +60,8 @@ extern "C" void sfm_ba_plan_destroy(sfm_ba_plan* p) {
   void* ptrs[] = {p->d_pt_ptr,   p->d_perm,     p->d_slot_cam, p->d_tp_ptr,  p->d_grp_pt,  p->d_cam_obs, p->d_pair_entry,
                   p->d_item_cam, p->d_item_beg, p->d_item_end, p->d_cam_item_ptr, p->d_blk_j, p->d_blk_k,
                   p->d_entries,  p->d_pit_blk,  p->d_pit_beg,  p->d_pit_end, p->d_pit_part, p->d_mb_blk,
-                  p->d_mb_part,  p->d_mb_cnt};
+                  p->d_mb_part,  p->d_mb_cnt,   p->d_run_pt0,  p->d_run_base, p->d_slot_obs, p->d_key_ptr,
+                  p->d_key_run};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   delete p;
@@ -238,6 +244,60 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   p->n_parts = n_parts;
   p->n_multi = (int32_t)mb_blk.size();
 
+  // ---- runs of the fused point-major assembly ----
+  // Every point's cameras must fit a window of 6 or 8 consecutive ids.  `group` consecutive
+  // first-cameras share a window (key = first camera / group, base camera = key * group); a run is
+  // a maximal range of consecutive points with one key, cut at multiples of pmax.  The rule needs
+  // no sequential pass either.
+  std::vector<int32_t> run_pt0, run_base, slot_obs, key_ptr, key_run;
+  {
+    int32_t span_max = 0;
+    bool empty_point = false;
+    for (int32_t i = 0; i < n; ++i) {
+      if (pt_ptr[i + 1] == pt_ptr[i]) {
+        empty_point = true;
+        continue;
+      }
+      span_max = std::max(span_max, slot_cam[pt_ptr[i + 1] - 1] - slot_cam[pt_ptr[i]] + 1);
+    }
+    FzShape sh;
+    if (fz_shape(n, span_max, empty_point, &sh)) {
+      int32_t prev_key = -1;
+      for (int32_t i = 0; i < n; ++i) {
+        const int32_t key = slot_cam[pt_ptr[i]] / sh.group;
+        if (i == 0 || key != prev_key || i % sh.pmax == 0) {
+          run_pt0.push_back(i);
+          run_base.push_back(key * sh.group);
+        }
+        prev_key = key;
+      }
+      const int32_t n_runs = (int32_t)run_pt0.size();
+      run_pt0.push_back(n);
+      if (fz_worthwhile(n, n_runs)) {
+        p->fz_slots = sh.slots;
+        p->fz_group = sh.group;
+        p->fz_pmax = sh.pmax;
+        p->n_runs = n_runs;
+        p->n_keys = (m - 1) / sh.group + 1;
+        slot_obs.assign((size_t)n * kFzLanesPerPoint, -1);
+        for (int32_t i = 0; i < n; ++i) {
+          const int32_t base = slot_cam[pt_ptr[i]] / sh.group * sh.group;
+          for (int32_t s = pt_ptr[i]; s < pt_ptr[i + 1]; ++s)
+            slot_obs[(size_t)i * kFzLanesPerPoint + (slot_cam[s] - base)] = perm[s];
+        }
+        key_ptr.assign(p->n_keys + 1, 0);
+        for (int32_t r = 0; r < n_runs; ++r) ++key_ptr[run_base[r] / sh.group + 1];
+        for (int32_t q = 0; q < p->n_keys; ++q) key_ptr[q + 1] += key_ptr[q];
+        key_run.resize(n_runs);
+        std::vector<int32_t> fill(key_ptr.begin(), key_ptr.end() - 1);
+        for (int32_t r = 0; r < n_runs; ++r) key_run[fill[run_base[r] / sh.group]++] = r;
+      } else {
+        run_pt0.clear();
+        run_base.clear();
+      }
+    }
+  }
+
   // ---- upload ----
   int rc = SFM_BA_OK;
   int64_t bytes = 0;
@@ -265,6 +325,13 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   up(mb_blk, &p->d_mb_blk);
   up(mb_part, &p->d_mb_part);
   up(mb_cnt, &p->d_mb_cnt);
+  if (p->n_runs > 0) {
+    up(run_pt0, &p->d_run_pt0);
+    up(run_base, &p->d_run_base);
+    up(slot_obs, &p->d_slot_obs);
+    up(key_ptr, &p->d_key_ptr);
+    up(key_run, &p->d_key_run);
+  }
   if (rc != SFM_BA_OK) {
     sfm_ba_plan_destroy(p);
     return rc;
@@ -315,6 +382,11 @@ extern "C" int sfm_ba_plan_read(const sfm_ba_plan* p, int field, void* h_dst, in
     case 18: src = p->d_mb_blk; count = p->n_multi; break;
     case 19: src = p->d_mb_part; count = p->n_multi; break;
     case 20: src = p->d_mb_cnt; count = p->n_multi; break;
+    case 21: src = p->d_run_pt0; count = p->n_runs > 0 ? p->n_runs + 1 : 0; break;
+    case 22: src = p->d_run_base; count = p->n_runs; break;
+    case 23: src = p->d_slot_obs; count = p->n_runs > 0 ? (int64_t)p->n * kFzLanesPerPoint : 0; break;
+    case 24: src = p->d_key_ptr; count = p->n_runs > 0 ? p->n_keys + 1 : 0; break;
+    case 25: src = p->d_key_run; count = p->n_runs; break;
     default: return SFM_BA_EINVAL;
   }
   *bytes_out = count * width;
@@ -328,6 +400,23 @@ extern "C" int32_t sfm_ba_plan_half_bandwidth(const sfm_ba_plan* p) {
   // two cameras j <= k share a point only if k - j <= max_cam_dist: the furthest non-zero of S from
   // its diagonal couples the first parameter of camera j with the last of camera j + max_cam_dist
   return p ? 7 * p->max_cam_dist + 6 : -1;
+}
+
+extern "C" int sfm_ba_plan_fused_info(const sfm_ba_plan* p, int32_t info[6]) {
+  if (!p || !info) return SFM_BA_EINVAL;
+  info[0] = p->n_runs > 0 && p->fz_enabled ? 1 : 0;
+  info[1] = p->fz_slots;
+  info[2] = p->fz_group;
+  info[3] = p->fz_pmax;
+  info[4] = p->n_runs;
+  info[5] = p->n_keys;
+  return SFM_BA_OK;
+}
+
+extern "C" int sfm_ba_plan_set_fused(sfm_ba_plan* p, int enable) {
+  if (!p) return SFM_BA_EINVAL;
+  p->fz_enabled = enable ? 1 : 0;
+  return SFM_BA_OK;
 }
 
 extern "C" int64_t sfm_ba_plan_workspace_bytes(const sfm_ba_plan* p) { return p ? p->ws_total : 0; }

@@ -40,7 +40,7 @@ struct Scratch {
 // statistics the host reads back between phases
 enum Stat {
   ST_MAX_CAM = 0, ST_MAX_PT, ST_NEGATIVE, ST_CAM_UNSORTED, ST_KMAX, ST_EMPTY_CAM, ST_EMPTY_PT, ST_NONUNIQUE,
-  ST_MAX_DIST, ST_COUNT
+  ST_MAX_DIST, ST_SPAN_MAX, ST_COUNT
 };
 
 __global__ void k_idx_stats(const int32_t* __restrict__ cam, const int32_t* __restrict__ pt, int64_t N,
@@ -270,6 +270,75 @@ __global__ void k_pair_items_fill(const int32_t* __restrict__ blk_ptr, const int
   }
 }
 
+// widest range of camera ids seen by one point (cameras ascend inside a point's slots)
+__global__ void k_point_span(const int32_t* __restrict__ pt_ptr, const int32_t* __restrict__ slot_cam, int32_t n,
+                             int32_t* __restrict__ stats) {
+  const int32_t i = blockIdx.x * kT + threadIdx.x;
+  if (i >= n) return;
+  const int32_t b = pt_ptr[i], e = pt_ptr[i + 1];
+  if (e > b) atomicMax(&stats[ST_SPAN_MAX], slot_cam[e - 1] - slot_cam[b] + 1);
+}
+
+// runs of the fused assembly: a point opens a run when its window key (first camera / group)
+// differs from its predecessor's or its id is a multiple of pmax
+__global__ void k_run_flags(const int32_t* __restrict__ pt_ptr, const int32_t* __restrict__ slot_cam, int32_t n,
+                            int32_t group, int32_t pmax, int32_t* __restrict__ flag) {
+  const int32_t i = blockIdx.x * kT + threadIdx.x;
+  if (i > n) return;
+  int32_t f = 0;
+  if (i < n) {
+    if (i == 0 || i % pmax == 0)
+      f = 1;
+    else
+      f = slot_cam[pt_ptr[i]] / group != slot_cam[pt_ptr[i - 1]] / group ? 1 : 0;
+  }
+  flag[i] = f;
+}
+
+__global__ void k_run_fill(const int32_t* __restrict__ flag, const int32_t* __restrict__ rid,
+                           const int32_t* __restrict__ pt_ptr, const int32_t* __restrict__ slot_cam, int32_t n,
+                           int32_t group, int32_t* __restrict__ run_pt0, int32_t* __restrict__ run_base,
+                           uint32_t* __restrict__ run_key, int32_t* __restrict__ run_id) {
+  const int32_t i = blockIdx.x * kT + threadIdx.x;
+  if (i > n) return;
+  if (i == n) {
+    run_pt0[rid[n]] = n;  // rid[n] = number of runs
+  } else if (flag[i]) {
+    const int32_t r = rid[i], key = slot_cam[pt_ptr[i]] / group;
+    run_pt0[r] = i;
+    run_base[r] = key * group;
+    run_key[r] = (uint32_t)key;
+    run_id[r] = r;
+  }
+}
+
+// observation of every (point, window slot)
+__global__ void k_slot_obs_fill(const int32_t* __restrict__ pt_ptr, const int32_t* __restrict__ slot_pt,
+                                const int32_t* __restrict__ slot_cam, const int32_t* __restrict__ perm, int64_t N,
+                                int32_t group, int32_t* __restrict__ slot_obs) {
+  const int64_t s = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (s >= N) return;
+  const int32_t i = slot_pt[s];
+  const int32_t base = slot_cam[pt_ptr[i]] / group * group;
+  slot_obs[(int64_t)i * kFzLanesPerPoint + (slot_cam[s] - base)] = perm[s];
+}
+
+// first position of every key in the sorted key list (lower bound), key_ptr[n_keys] = n_runs
+__global__ void k_key_ptr(const uint32_t* __restrict__ sorted_key, int32_t n_runs, int32_t n_keys,
+                          int32_t* __restrict__ key_ptr) {
+  const int32_t q = blockIdx.x * kT + threadIdx.x;
+  if (q > n_keys) return;
+  int32_t lo = 0, hi = n_runs;
+  while (lo < hi) {
+    const int32_t mid = (lo + hi) >> 1;
+    if (sorted_key[mid] < (uint32_t)q)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  key_ptr[q] = lo;
+}
+
 template <typename T>
 int scan_exclusive(const T* in, T* out, int64_t count, Scratch& scratch, hipStream_t st) {
   size_t bytes = 0;
@@ -325,7 +394,7 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
     return SFM_BA_OK;
   };
   {
-    int32_t init[ST_COUNT] = {-1, -1, 0, 0, 0, 0, 0, 0, 0};
+    int32_t init[ST_COUNT] = {-1, -1, 0, 0, 0, 0, 0, 0, 0, 0};
     SFMBA_HIP(hipMemcpyAsync(d_stats, init, sizeof(init), hipMemcpyHostToDevice, st));
     SFMBA_HIP(hipStreamSynchronize(st));  // `init` leaves scope
   }
@@ -392,12 +461,15 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
   k_idx_keys<<<blocks_for(N), kT, 0, st>>>(cam, pt, N, cam_bits, key64, ident, cam_key);
   SFMBA_TRY(sort_pairs(key64, key64_sorted, ident, p->d_perm, N, cam_bits + pt_bits, scratch, st));
   k_idx_unpack<<<blocks_for(N), kT, 0, st>>>(key64_sorted, N, cam_bits, p->d_slot_cam, slot_pt, d_stats);
+  k_point_span<<<blocks_for(n), kT, 0, st>>>(p->d_pt_ptr, p->d_slot_cam, n, d_stats);
   if (!cam_sorted) {
     SFMBA_TRY(keep(&p->d_cam_obs, N, &bytes));
     SFMBA_TRY(sort_pairs(cam_key, cam_key + N, ident, p->d_cam_obs, N, cam_bits, scratch, st));
   }
   SFMBA_TRY(read_stats());
   if (check && h[ST_NONUNIQUE]) return SFM_BA_ENONUNIQUE;
+  const int32_t span_max = h[ST_SPAN_MAX];
+  const bool empty_point = h[ST_EMPTY_PT] != 0;
   if (kmax > SFM_BA_MAX_VIEWS || kmax > kGroupSlots) return SFM_BA_ETOOBIG;
   if (N * 112 >= (int64_t(1) << 32)) return SFM_BA_ETOOBIG;  // 32-bit byte offsets into A
   // 32-bit byte offsets into T, counted from the start of g that precedes it in the workspace
@@ -498,6 +570,43 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
   SFMBA_TRY(keep(&p->d_mb_cnt, totals[1], &bytes));
   k_pair_items_fill<<<blocks_for(nb), kT, 0, st>>>(blk_ptr, item_off, multi_off, part_off, nb, p->d_pit_blk, p->d_pit_beg,
                                                    p->d_pit_end, p->d_pit_part, p->d_mb_blk, p->d_mb_part, p->d_mb_cnt);
+
+  // ---- runs of the fused point-major assembly (same rule as the host builder) ----
+  FzShape sh;
+  if (fz_shape(n, span_max, empty_point, &sh)) {
+    int32_t *flag, *rid;
+    SFMBA_HIP(scratch.get(&flag, n + 1));
+    SFMBA_HIP(scratch.get(&rid, n + 1));
+    k_run_flags<<<blocks_for(n + 1), kT, 0, st>>>(p->d_pt_ptr, p->d_slot_cam, n, sh.group, sh.pmax, flag);
+    SFMBA_TRY(scan_exclusive(flag, rid, n + 1, scratch, st));
+    int32_t n_runs = 0;
+    SFMBA_HIP(hipMemcpyAsync(&n_runs, rid + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SFMBA_HIP(hipStreamSynchronize(st));
+    if (fz_worthwhile(n, n_runs)) {
+      p->fz_slots = sh.slots;
+      p->fz_group = sh.group;
+      p->fz_pmax = sh.pmax;
+      p->n_runs = n_runs;
+      p->n_keys = (m - 1) / sh.group + 1;
+      uint32_t *run_key, *run_key_sorted;
+      int32_t* run_id;
+      SFMBA_HIP(scratch.get(&run_key, n_runs));
+      SFMBA_HIP(scratch.get(&run_key_sorted, n_runs));
+      SFMBA_HIP(scratch.get(&run_id, n_runs));
+      SFMBA_TRY(keep(&p->d_run_pt0, n_runs + 1, &bytes));
+      SFMBA_TRY(keep(&p->d_run_base, n_runs, &bytes));
+      SFMBA_TRY(keep(&p->d_slot_obs, (int64_t)n * kFzLanesPerPoint, &bytes));
+      SFMBA_TRY(keep(&p->d_key_ptr, p->n_keys + 1, &bytes));
+      SFMBA_TRY(keep(&p->d_key_run, n_runs, &bytes));
+      k_run_fill<<<blocks_for(n + 1), kT, 0, st>>>(flag, rid, p->d_pt_ptr, p->d_slot_cam, n, sh.group, p->d_run_pt0,
+                                                  p->d_run_base, run_key, run_id);
+      SFMBA_HIP(hipMemsetAsync(p->d_slot_obs, 0xFF, sizeof(int32_t) * (size_t)n * kFzLanesPerPoint, st));
+      k_slot_obs_fill<<<blocks_for(N), kT, 0, st>>>(p->d_pt_ptr, slot_pt, p->d_slot_cam, p->d_perm, N, sh.group,
+                                                   p->d_slot_obs);
+      SFMBA_TRY(sort_pairs(run_key, run_key_sorted, run_id, p->d_key_run, n_runs, bits_for(p->n_keys), scratch, st));
+      k_key_ptr<<<blocks_for(p->n_keys + 1), kT, 0, st>>>(run_key_sorted, n_runs, p->n_keys, p->d_key_ptr);
+    }
+  }
   SFMBA_HIP(hipGetLastError());
   SFMBA_HIP(hipStreamSynchronize(st));
   p->device_bytes = bytes;

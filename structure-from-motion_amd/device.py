@@ -43,7 +43,7 @@ class Plan:
 
     FIELDS = ("pt_ptr", "perm", "slot_cam", "tp_ptr", "pair_entry", "grp_pt", "cam_obs", "item_cam", "item_beg",
               "item_end", "cam_item_ptr", "blk_j", "blk_k", "entries", "pit_blk", "pit_beg", "pit_end", "pit_part",
-              "mb_blk", "mb_part", "mb_cnt")
+              "mb_blk", "mb_part", "mb_cnt", "run_pt0", "run_base", "slot_obs", "key_ptr", "key_run")
 
     def __init__(self, cam_idx, pt_idx, n_cams_hint=0, n_pts_hint=0, check=True, where="device"):
         lib = _lib.load()
@@ -79,6 +79,15 @@ class Plan:
          self.n_items, self.device_bytes) = [int(v) for v in sizes]
         self.workspace_bytes = int(lib.sfm_ba_plan_workspace_bytes(handle))
         self.half_bandwidth = int(lib.sfm_ba_plan_half_bandwidth(handle))
+        info = (C.c_int32 * 6)()
+        _lib.check(lib.sfm_ba_plan_fused_info(handle, info))
+        # runs of the fused point-major assembly (0 runs: the visibility pattern does not allow it)
+        (self.fused, self.fused_slots, self.fused_group, self.fused_pmax, self.n_runs, self.n_keys) = [int(v) for v in info]
+
+    def set_fused(self, enable):
+        """Turn the fused point-major assembly of this plan on or off (on by default where runs exist)."""
+        _lib.check(self._lib.sfm_ba_plan_set_fused(self.handle, int(bool(enable))))
+        self.fused = int(bool(enable) and self.n_runs > 0)
 
     def read(self, field):
         """One index array of the plan as a host array (``entries``: uint32 (n, 2))."""

@@ -1,7 +1,10 @@
 // Host-only check of the visibility plan: builds the plan with device allocation replaced by host
 // memory and verifies the invariants the kernels rely on.  Usage: plan_check m n k mode seed
 //   mode 0: every point is seen by k cameras drawn uniformly; mode 1: by k consecutive cameras
-//   around a centre that moves with the point index (banded).
+//   around a centre that moves with the point index (banded); mode 2: by k consecutive cameras from
+//   a first camera that ascends with the point index (the order in which an incremental
+//   reconstruction creates points).  Optional sixth argument: 1 / 0 =
+//   the plan must / must not hold runs of the fused assembly.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -37,9 +40,12 @@ int main(int argc, char** argv) {
     const int kk = 2 + (int)(rng() % (unsigned)(k - 1));  // 2..k views
     if (mode == 0) {
       while ((int)cs.size() < std::min(kk, m)) cs.insert((int)(rng() % (unsigned)m));
-    } else {
+    } else if (mode == 1) {
       const int c0 = (int)((int64_t)i * m / n);
       for (int q = 0; q < kk; ++q) cs.insert(std::min(m - 1, std::max(0, c0 - kk / 2 + q)));
+    } else {
+      const int c0 = (int)((int64_t)i * m / n);
+      for (int q = 0; q < kk; ++q) cs.insert(std::min(m - 1, c0 + q));
     }
     for (int c : cs) {
       cam.push_back(c);
@@ -111,7 +117,40 @@ int main(int argc, char** argv) {
     REQUIRE((p->d_pit_part[it] < 0) == (blk_items[(size_t)p->d_pit_blk[it]] == 1));
   // every block has entries
   for (int b = 0; b < p->n_blocks; ++b) REQUIRE(blk_items[(size_t)b] >= 1);
-  printf("ok m=%d n=%d N=%lld blocks=%d entries=%lld items=%d parts=%d half_bandwidth=%d\n", m, n, (long long)N,
+  // runs of the fused assembly: they tile the points, every observation sits at the slot of its
+  // camera in its run's window, every other slot is empty, and the runs are grouped by window
+  if (p->n_runs > 0) {
+    REQUIRE(p->fz_slots == 6 || p->fz_slots == 8);
+    REQUIRE(p->fz_group >= 1 && p->fz_pmax >= 8);
+    REQUIRE(p->d_run_pt0[0] == 0 && p->d_run_pt0[p->n_runs] == n);
+    std::vector<int64_t> seen_obs((size_t)N, 0);
+    for (int r = 0; r < p->n_runs; ++r) {
+      const int b = p->d_run_base[r];
+      REQUIRE(p->d_run_pt0[r + 1] > p->d_run_pt0[r] && p->d_run_pt0[r + 1] - p->d_run_pt0[r] <= p->fz_pmax);
+      REQUIRE(b >= 0 && b % p->fz_group == 0);
+      for (int i = p->d_run_pt0[r]; i < p->d_run_pt0[r + 1]; ++i)
+        for (int sl = 0; sl < 8; ++sl) {
+          const int32_t o = p->d_slot_obs[(size_t)i * 8 + sl];
+          if (o < 0) continue;
+          REQUIRE(sl < p->fz_slots && o < N && pt[(size_t)o] == i && cam[(size_t)o] == b + sl);
+          ++seen_obs[(size_t)o];
+        }
+    }
+    for (int64_t o = 0; o < N; ++o) REQUIRE(seen_obs[(size_t)o] == 1);
+    REQUIRE(p->n_keys == (m - 1) / p->fz_group + 1);
+    REQUIRE(p->d_key_ptr[0] == 0 && p->d_key_ptr[p->n_keys] == p->n_runs);
+    std::vector<char> run_hit((size_t)p->n_runs, 0);
+    for (int q = 0; q < p->n_keys; ++q)
+      for (int i = p->d_key_ptr[q]; i < p->d_key_ptr[q + 1]; ++i) {
+        const int r = p->d_key_run[i];
+        REQUIRE(r >= 0 && r < p->n_runs && !run_hit[(size_t)r] && p->d_run_base[r] == q * p->fz_group);
+        REQUIRE(i == p->d_key_ptr[q] || p->d_key_run[i - 1] < r);
+        run_hit[(size_t)r] = 1;
+      }
+  }
+  if (argc > 6) REQUIRE((p->n_runs > 0) == (atoi(argv[6]) != 0));
+  printf("ok runs=%d slots=%d group=%d pmax=%d ", p->n_runs, p->fz_slots, p->fz_group, p->fz_pmax);
+  printf("m=%d n=%d N=%lld blocks=%d entries=%lld items=%d parts=%d half_bandwidth=%d\n", m, n, (long long)N,
          p->n_blocks, (long long)E, p->n_pair_items, p->n_parts, sfm_ba_plan_half_bandwidth(p));
   sfm_ba_plan_destroy(p);
   return 0;
