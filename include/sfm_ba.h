@@ -87,9 +87,10 @@ void sfm_ba_plan_destroy(sfm_ba_plan* plan);
  * 2 slot_cam, 3 tp_ptr, 4 pair_entry, 5 grp_pt, 6 cam_obs (empty when the caller order is
  * camera-sorted), 7-9 per-camera items (camera, begin, end), 10 cam_item_ptr, 11-12 block cameras
  * (j, k), 13 pair entries (two uint32 each), 14-17 pair items (block, begin, end, partial), 18-20
- * split blocks (block, first partial, partials), 21-25 runs of the fused assembly (first point of
+ * split blocks (block, first partial, partials), 21-26 runs of the fused assembly (first point of
  * each run, base camera, observation per (point, window slot), runs grouped by window: row pointer
- * and run ids; all empty when the plan has no runs).  *bytes receives the array's size; h_dst may be
+ * and run ids, first run of every range of points that one wave walks; all empty when the plan has
+ * no runs).  *bytes receives the array's size; h_dst may be
  * null to query it, otherwise `capacity` must be at least that size. */
 int sfm_ba_plan_read(const sfm_ba_plan* plan, int field, void* h_dst, int64_t capacity, int64_t* bytes);
 /* sizes: what[0]=n_cams, [1]=n_pts, [2]=n_obs, [3]=number of camera-pair blocks (j<=k) with a shared

@@ -25,7 +25,7 @@ constexpr int kFzLanesPerPoint = 8;  // lanes (= slot positions of the table) pe
 constexpr int kFzSlotRec = 40;       // doubles per camera slot behind a partial's tiles: 28 (upper triangle of
                                      // sum A^T A) + 7 (sum A^T g), padded
 struct FzShape {
-  int slots;  // camera slots of a window: 6 or 8 (3 or 4 row tiles of 16 = two cameras of 8 rows each)
+  int slots;  // camera slots of a window: 4 .. 8
   int group;  // consecutive first-cameras that share a window: slots - span + 1
   int pmax;   // a run is cut wherever the point id is a multiple of this
 };
@@ -33,7 +33,7 @@ struct FzShape {
 // fused path does not apply (a point without observations, or a span beyond 8 cameras).
 inline bool fz_shape(int32_t n, int32_t span_max, bool empty_point, FzShape* o) {
   if (empty_point || span_max < 1 || span_max > 8) return false;
-  o->slots = span_max <= 6 ? 6 : 8;
+  o->slots = span_max < 4 ? 4 : span_max;
   o->group = o->slots - span_max + 1;
   int pm = ((n + 2047) / 2048 + 7) & ~7;
   o->pmax = pm < 32 ? 32 : (pm > 1024 ? 1024 : pm);
@@ -41,8 +41,16 @@ inline bool fz_shape(int32_t n, int32_t span_max, bool empty_point, FzShape* o) 
 }
 // runs must be long enough for their fixed cost (one partial result each) to be small
 inline bool fz_worthwhile(int32_t n, int32_t n_runs) { return (int64_t)n_runs * 24 <= (int64_t)n + 1536; }
-__host__ __device__ inline int fz_tiles(int slots) { return (slots / 2) * (slots / 2 + 1) / 2; }
-__host__ __device__ inline int64_t fz_part_stride(int slots) { return (int64_t)fz_tiles(slots) * 256 + 8 * kFzSlotRec; }
+// the 7 * slots rows of a window: 16 per row tile of the matrix cores, the rest ("extra rows") summed by the lanes
+__host__ __device__ inline int fz_row_tiles(int slots) { return slots <= 5 ? 2 : (slots <= 7 ? 3 : 4); }
+__host__ __device__ inline int fz_extra_rows(int slots) { return slots == 5 ? 3 : (slots == 7 ? 1 : 0); }
+// doubles of one partial result: lower-triangle tiles (16 x 16), extra rows (64 each), 8 slot records
+__host__ __device__ constexpr int64_t fz_part_stride_c(int tiles, int extra) {
+  return (int64_t)(tiles * (tiles + 1) / 2) * 256 + extra * 64 + 8 * kFzSlotRec;
+}
+__host__ __device__ inline int64_t fz_part_stride(int slots) {
+  return fz_part_stride_c(fz_row_tiles(slots), fz_extra_rows(slots));
+}
 
 struct PairEntry {
   uint32_t row_a;  // 112 * observation (caller order) of the block's row camera j: its row of A
@@ -93,9 +101,10 @@ struct sfm_ba_plan {
   int32_t* d_mb_cnt = nullptr;    // number of partials
   // fused point-major assembly (fz_slots = 0: the visibility pattern does not allow it)
   int32_t fz_slots = 0, fz_group = 0, fz_pmax = 0, fz_enabled = 1;
-  int32_t n_runs = 0, n_keys = 0;
+  int32_t n_runs = 0, n_keys = 0, n_ranges = 0;
   int32_t* d_run_pt0 = nullptr;   // [n_runs+1] first point of each run
   int32_t* d_run_base = nullptr;  // [n_runs] first camera of the run's window
+  int32_t* d_rng_run = nullptr;   // [n_ranges+1] first run of every range of fz_pmax points (one wave per range)
   int32_t* d_slot_obs = nullptr;  // [n][8] observation (caller order) of point i at camera base + slot, or -1
   int32_t* d_key_ptr = nullptr;   // [n_keys+1] runs grouped by window (key = base / group), ascending run id
   int32_t* d_key_run = nullptr;   // [n_runs]

@@ -4,11 +4,15 @@
 // Applies when the plan found "runs": ranges of consecutive points whose cameras all lie in a window
 // of 6 or 8 consecutive camera ids (the visibility an incremental reconstruction produces).  Then
 //   S_window -= sum_i Y_i W_i^T,   Y_i = W_i V_i^-1,   W_i = [A_ij^T B_ij]_j  (7 rows per camera j)
-// is a dense contraction over the points of the run: with V_i^-1 = L_i L_i^T and Z_i = W_i L_i it is
-// the symmetric rank-3 update sum_i Z_i Z_i^T, and a wave accumulates it with v_mfma_f64_16x16x4
-// (16 rows = two cameras of 7 parameters + 1 padding row each; K = 3 columns per point).
+// is a dense contraction over the points of the run: with V_i^-1 = G_i^T G_i and Z_i = W_i G_i^T it
+// is the symmetric rank-3 update sum_i Z_i Z_i^T, and a wave accumulates it with v_mfma_f64_16x16x4
+// (rows 7 slot + r of the window, K = 3 columns per point).  On gfx950 the fp64 MFMA and the fp64
+// vector instructions of a SIMD share one pipe (they do not overlap, measured with
+// scripts/probes/dp_coexec.hip), so the kernel's time is the sum of its MFMA and VALU cycles: the
+// window is as small as the visibility allows (no tile of padding) and the per-point arithmetic
+// avoids divisions.
 //
-// One wave per run, no barriers.  Lane (p, s) of a step owns the observation of point p (8 points per
+// One wave per range of pmax points (a range holds whole runs), no barriers.  Lane (p, s) of a step owns the observation of point p (8 points per
 // step) by the camera at slot s of the window (or none: it then contributes zeros):
 //   1. the row of A, x_true and x_pred come straight into registers (loads for the next step are
 //      issued before the matrix phase of this one);
@@ -20,6 +24,8 @@
 // At the end of the run the wave stores its tiles and per-slot sums as one partial result.  Partials
 // are added in a fixed order (k_fused_reduce: runs of one window; k_fused_finish: windows of one
 // camera pair), so results are reproducible bit for bit.
+#include <cstdlib>
+
 #include "ba_common.h"
 
 namespace sfmba {
@@ -48,6 +54,15 @@ __device__ __forceinline__ double sum8(double v) {
   return v;
 }
 
+// value of lane SX (0..7) of this lane's group of 8, in every lane of the group
+template <int SX>
+__device__ __forceinline__ double bcast8(double v, int s) {
+  constexpr int c = SX & 3;
+  const double t = dpp64<(c | (c << 2) | (c << 4) | (c << 6))>(v);  // every quad: its lane c
+  const double o = dpp64<0x141>(t);                                  // row_half_mirror: the other quad's
+  return (s >> 2) == (SX >> 2) ? t : o;
+}
+
 // sum over the 8 lanes that share lane & 7
 __device__ __forceinline__ double sum_over_points(double v) {
   v += dpp64<0x128>(v);  // row_ror:8 = lane ^ 8 inside a row of 16
@@ -56,29 +71,64 @@ __device__ __forceinline__ double sum_over_points(double v) {
   return v;
 }
 
-template <int T>  // row tiles of 16: 3 (6 camera slots) or 4 (8 slots)
-__global__ __launch_bounds__(64, 2) void k_fused_runs(
-    const int32_t* __restrict__ run_pt0, const int32_t* __restrict__ slot_obs, const double* __restrict__ A,
+// 1 / sqrt(x): hardware estimate refined by three Newton steps (the estimate is good to roughly
+// single precision; the third step is there for margin).  No special cases: x is a positive pivot.
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double t = x * y;
+    const double e = fma(-t, y, 1.0);
+    y = fma(0.5 * y, e, y);
+  }
+  return y;
+}
+
+// W camera slots per window, rows 7 slot + r (dense: no padding rows between cameras); the first
+// 16 T rows go through the matrix cores, the E rows behind them are accumulated by the lanes
+// themselves (21 FMAs per row and step: cheaper than another row of tiles for E <= 3).
+//   W = 4: T 2, E 0 (28 rows)   W = 5: T 2, E 3 (35)   W = 6: T 3, E 0 (42)   W = 7: T 3, E 1 (49)
+//   W = 8: T 4, E 0 (56)
+template <int W, int T, int E, int WPS>  // WPS: waves per SIMD the register allocation leaves room for
+__global__ __launch_bounds__(64, WPS) void k_fused_runs(
+    const int32_t* __restrict__ rng_run, const int32_t* __restrict__ run_pt0,
+    const int32_t* __restrict__ slot_obs, const double* __restrict__ A,
     const double* __restrict__ xt, const double* __restrict__ xp, double mu, double* __restrict__ Vinv,
     double* __restrict__ eps_b, double* __restrict__ part) {
-  constexpr int KS = 16 * T;  // rows of the panel
+  static_assert(16 * T + E >= 7 * W && 16 * T <= 7 * W + 15, "tiles and extra rows must cover the window");
+  static_assert(E == 0 || (16 * T) / 7 == (16 * T + E - 1) / 7, "the extra rows belong to one camera slot");
+  static_assert(E == 0 || (16 * T) / 7 == 4 || (16 * T) / 7 == 6, "extra rows are wired for slots 4 and 6");
+  constexpr int KS = 64;  // doubles per K column of the panel: 8 per camera slot (7 rows + a zero)
   constexpr int NT = T * (T + 1) / 2;
-  constexpr int64_t STRIDE = (int64_t)NT * 256 + 8 * kFzSlotRec;
-  __shared__ __attribute__((aligned(16))) double Zp[24 * KS];  // [K column = 3 point + q][row = 8 slot + r]
+  constexpr int64_t STRIDE = fz_part_stride_c(T, E);
+  __shared__ __attribute__((aligned(16))) double Zp[24 * KS];  // [K column = 3 point + q][8 slot + r]
   const int lane = threadIdx.x;
   const int p = lane >> 3, s = lane & 7;
   const int li = lane & 15, lk = lane >> 4;
-  const int run = blockIdx.x;
+  // panel offset of dense row 16 t + li for the operand reads (rows past the window: a zero entry)
+  int roff[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int rho = 16 * t + li;
+    roff[t] = rho < 7 * W ? 8 * (rho / 7) + rho % 7 : 7;
+  }
+  // a wave walks the runs of one range of points (ranges hold equal numbers of points)
+  const int run_end = rng_run[blockIdx.x + 1];
+  for (int run = rng_run[blockIdx.x]; run < run_end; ++run) {
   const int pt0 = run_pt0[run], pt1 = run_pt0[run + 1];
 
   d4_t acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = d4_t{0.0, 0.0, 0.0, 0.0};
-  double u[28], ev[7];
+  double u[28], ev[7], xa[E > 0 ? E : 1][7];
 #pragma unroll
   for (int i = 0; i < 28; ++i) u[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < 7; ++i) ev[i] = 0.0;
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) xa[e][i] = 0.0;
 
   // slot table entry of this lane for the step that starts at point `first` (-1: no observation)
 #define FZ_FETCH_POS(first) (((first) + p) < pt1 ? slot_obs[kFzLanesPerPoint * (int64_t)((first) + p) + s] : -1)
@@ -102,12 +152,16 @@ __global__ __launch_bounds__(64, 2) void k_fused_runs(
   double a[18];
   int pos = FZ_FETCH_POS(pt0);
   int pos_next = FZ_FETCH_POS(pt0 + 8);
+  int pos_next2 = FZ_FETCH_POS(pt0 + 16);
   FZ_FETCH_ROWS(pos);
 
   for (int first = pt0; first < pt1; first += 8) {
     const int pt = first + p;
-    // ---- per observation: point block (minus the camera-centre columns of A), residual ----
-    const double b0 = -a[4], b1 = -a[5], b2 = -a[6], b3 = -a[11], b4 = -a[12], b5 = -a[13];
+    // ---- per observation: point block and residual.  The point block B is minus the camera-centre
+    // columns of A; the arithmetic below works with b = -B (those columns as they are): V = b^T b,
+    // q = b^T eps = -eps_b, g = eps + b V^-1 q, and Z comes out with the opposite sign, which Z Z^T
+    // does not see ----
+    const double b0 = a[4], b1 = a[5], b2 = a[6], b3 = a[11], b4 = a[12], b5 = a[13];
     const double e0 = a[14] - a[16], e1 = a[15] - a[17];
     // B^T B (00 01 02 11 12 22) and B^T eps, summed over the observations of the point
     const double v00 = sum8(b0 * b0 + b3 * b3) + mu;
@@ -119,16 +173,25 @@ __global__ __launch_bounds__(64, 2) void k_fused_runs(
     const double q0 = sum8(b0 * e0 + b3 * e1);
     const double q1 = sum8(b1 * e0 + b4 * e1);
     const double q2 = sum8(b2 * e0 + b5 * e1);
-    // V^-1 in closed form (V is symmetric positive definite for mu > 0)
-    const double c00 = v11 * v22 - v12 * v12;
-    const double c01 = v02 * v12 - v01 * v22;
-    const double c02 = v01 * v12 - v02 * v11;
-    const double c11 = v00 * v22 - v02 * v02;
-    const double c12 = v01 * v02 - v00 * v12;
-    const double c22 = v00 * v11 - v01 * v01;
-    const double det = v00 * c00 + v01 * c01 + v02 * c02;
-    const double id = 1.0 / det;
-    const double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id, i11 = c11 * id, i12 = c12 * id, i22 = c22 * id;
+    // V = C C^T (V is symmetric positive definite for mu > 0), G = C^-1 (lower triangular):
+    // V^-1 = G^T G, and Z = W G^T satisfies Z Z^T = W V^-1 W^T.  No division: the reciprocal
+    // square roots of the pivots are all that is needed.
+    const double r0 = rsqrt_nr(v00);
+    const double c10 = v01 * r0, c20 = v02 * r0;
+    const double d1 = fma(-c10, c10, v11);
+    const double r1 = rsqrt_nr(d1);
+    const double c21 = fma(-c20, c10, v12) * r1;
+    const double d2 = fma(-c21, c21, fma(-c20, c20, v22));
+    const double r2 = rsqrt_nr(d2);
+    const double g10 = -c10 * r0 * r1;
+    const double g21 = -c21 * r1 * r2;
+    const double g20 = -(c20 * r0 + c21 * g10) * r2;
+    const double i00 = fma(g20, g20, fma(g10, g10, r0 * r0));
+    const double i01 = fma(g20, g21, g10 * r1);
+    const double i02 = g20 * r2;
+    const double i11 = fma(g21, g21, r1 * r1);
+    const double i12 = g21 * r2;
+    const double i22 = r2 * r2;
     if (pt < pt1) {
       // lane s < 3 of the point stores row s of V^-1 and entry s of eps_b.  Three masked blocks on
       // laundered copies of s: a selection by s (of values or of addresses) is turned into a table
@@ -139,15 +202,19 @@ __global__ __launch_bounds__(64, 2) void k_fused_runs(
       asm volatile("" : "+v"(sa));
       asm volatile("" : "+v"(sb));
       asm volatile("" : "+v"(sc));
-      if (sa == 0) { vo[0] = i00; vo[1] = i01; vo[2] = i02; eo[0] = q0; }
-      if (sb == 1) { vo[3] = i01; vo[4] = i11; vo[5] = i12; eo[1] = q1; }
-      if (sc == 2) { vo[6] = i02; vo[7] = i12; vo[8] = i22; eo[2] = q2; }
+      if (sa == 0) { vo[0] = i00; vo[1] = i01; vo[2] = i02; eo[0] = -q0; }
+      if (sb == 1) { vo[3] = i01; vo[4] = i11; vo[5] = i12; eo[1] = -q1; }
+      if (sc == 2) { vo[6] = i02; vo[7] = i12; vo[8] = i22; eo[2] = -q2; }
     }
     const double z0 = i00 * q0 + i01 * q1 + i02 * q2;
     const double z1 = i01 * q0 + i11 * q1 + i12 * q2;
     const double z2 = i02 * q0 + i12 * q1 + i22 * q2;
-    const double g0 = e0 - (b0 * z0 + b1 * z1 + b2 * z2);
+    const double g0 = e0 - (b0 * z0 + b1 * z1 + b2 * z2);  // (-B)(-V^-1 eps_b) = B V^-1 eps_b
     const double g1 = e1 - (b3 * z0 + b4 * z1 + b5 * z2);
+    // ---- B G^T (2 x 3): column q is sum_{a <= q} B[:, a] G[q][a]; then Z = A^T (B G^T) ----
+    const double m00 = b0 * r0, m01 = fma(b1, r1, b0 * g10), m02 = fma(b2, r2, fma(b1, g21, b0 * g20));
+    const double m10 = b3 * r0, m11 = fma(b4, r1, b3 * g10), m12 = fma(b5, r2, fma(b4, g21, b3 * g20));
+    __builtin_amdgcn_sched_barrier(0);  // (phases kept apart: interleaving them costs registers)
     // ---- per camera slot: U_j += A^T A, e_j += A^T g ----
     {
       int v = 0;
@@ -158,16 +225,32 @@ __global__ __launch_bounds__(64, 2) void k_fused_runs(
         ev[r] = fma(a[7 + r], g1, fma(a[r], g0, ev[r]));
       }
     }
-    // ---- Z = A^T (B L), V^-1 = L L^T ----
-    const double l00 = sqrt(i00);
-    const double rl0 = 1.0 / l00;
-    const double l10 = i01 * rl0, l20 = i02 * rl0;
-    const double l11 = sqrt(i11 - l10 * l10);
-    const double l21 = (i12 - l20 * l10) / l11;
-    const double l22 = sqrt(i22 - l20 * l20 - l21 * l21);
-    const double m00 = b0 * l00 + b1 * l10 + b2 * l20, m01 = b1 * l11 + b2 * l21, m02 = b2 * l22;
-    const double m10 = b3 * l00 + b4 * l10 + b5 * l20, m11 = b4 * l11 + b5 * l21, m12 = b5 * l22;
-    if (s < 2 * T) {
+    // ---- rows behind the tiles: D[x][7 s + r] += sum_q Z_x[q] Z_s[r][q] with Z_s[r][q] = A_s[:, r] . M_s[:, q]
+    // is A_s[:, r] . h, h = M_s Z_x^T: the same shape as e_j.  Z_x (row x of the panel's slot sx) comes
+    // from lane sx of the point by DPP ----
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      constexpr int dummy = 16 * T;
+      const int rho = dummy + e;
+      const int rx = rho % 7;
+      const double w0 = fma(a[7 + rx], m10, a[rx] * m00);
+      const double w1 = fma(a[7 + rx], m11, a[rx] * m01);
+      const double w2 = fma(a[7 + rx], m12, a[rx] * m02);
+      double x0, x1, x2;
+      if ((dummy + e) / 7 == 4) {
+        x0 = bcast8<4>(w0, s); x1 = bcast8<4>(w1, s); x2 = bcast8<4>(w2, s);
+      } else {
+        x0 = bcast8<6>(w0, s); x1 = bcast8<6>(w1, s); x2 = bcast8<6>(w2, s);
+      }
+      const double h0 = fma(x2, m02, fma(x1, m01, x0 * m00));
+      const double h1 = fma(x2, m12, fma(x1, m11, x0 * m10));
+#pragma unroll
+      for (int r = 0; r < 7; ++r) xa[e][r] = fma(a[7 + r], h1, fma(a[r], h0, xa[e][r]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- Z into the panel (slots at and beyond W never hold an observation: their lanes write the
+    // zeros that the operand reads of rows past the window pick up at offset 7) ----
+    {
       double* zp = Zp + (3 * p) * KS + 8 * s;
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
@@ -175,26 +258,27 @@ __global__ __launch_bounds__(64, 2) void k_fused_runs(
         const double mb = q == 0 ? m10 : (q == 1 ? m11 : m12);
         double z[7];
 #pragma unroll
-        for (int r = 0; r < 7; ++r) z[r] = a[r] * ma + a[7 + r] * mb;
+        for (int r = 0; r < 7; ++r) z[r] = fma(a[7 + r], mb, a[r] * ma);
         sts2(zp + q * KS, z[0], z[1]);
         sts2(zp + q * KS + 2, z[2], z[3]);
         sts2(zp + q * KS + 4, z[4], z[5]);
         sts2(zp + q * KS + 6, z[6], 0.0);
       }
     }
-    // ---- next step's operands on their way while the matrix cores work ----
-    pos = pos_next;
-    FZ_FETCH_ROWS(pos);
-    pos_next = FZ_FETCH_POS(first + 16);
     // one wave wrote the panel and reads it: its LDS operations complete in order
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- next step's operands on their way while the matrix cores work ----
+    pos = pos_next;
+    FZ_FETCH_ROWS(pos);
+    pos_next = pos_next2;
+    pos_next2 = FZ_FETCH_POS(first + 24);
 #pragma unroll
     for (int kk = 0; kk < 6; ++kk) {
       double zt[T];
 #pragma unroll
-      for (int t = 0; t < T; ++t) zt[t] = Zp[(4 * kk + lk) * KS + 16 * t + li];
+      for (int t = 0; t < T; ++t) zt[t] = Zp[(4 * kk + lk) * KS + roff[t]];
       int idx = 0;
 #pragma unroll
       for (int ti = 0; ti < T; ++ti)
@@ -205,17 +289,23 @@ __global__ __launch_bounds__(64, 2) void k_fused_runs(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-
 #undef FZ_FETCH_POS
 #undef FZ_FETCH_ROWS
 
-  // ---- the run's partial result: tiles as they lie in the registers, then the per-slot sums ----
+  // ---- the run's partial result: tiles as they lie in the registers, the extra rows, the per-slot sums ----
   double* po = part + (int64_t)run * STRIDE;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int v = 0; v < 4; ++v) po[t * 256 + (lk + 4 * v) * 16 + li] = acc[t][v];
-  double* uo = po + NT * 256 + s * kFzSlotRec;
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const double v = sum_over_points(xa[e][i]);
+      if (p == 0) po[NT * 256 + e * 64 + 8 * s + i] = v;
+    }
+  double* uo = po + NT * 256 + E * 64 + s * kFzSlotRec;
 #pragma unroll
   for (int i = 0; i < 28; ++i) {
     const double v = sum_over_points(u[i]);
@@ -226,6 +316,7 @@ __global__ __launch_bounds__(64, 2) void k_fused_runs(
     const double v = sum_over_points(ev[i]);
     if (p == 0) uo[28 + i] = v;
   }
+  }  // runs of the range
 }
 
 // partial results of the runs of one window, added in run order
@@ -260,8 +351,9 @@ __global__ __launch_bounds__(64) void k_fused_finish(const int32_t* __restrict__
   const int t = threadIdx.x;
   const int j = blk_j[blockIdx.x], k = blk_k[blockIdx.x];
   if (t >= 56 || (t >= 49 && j != k)) return;
-  const int nt = fz_tiles(slots);
-  const int64_t stride = fz_part_stride(slots);
+  const int T = fz_row_tiles(slots), E = fz_extra_rows(slots);
+  const int nt = T * (T + 1) / 2;
+  const int64_t stride = fz_part_stride_c(T, E);
   const int lo = k - slots + 1 > 0 ? k - slots + 1 : 0;
   const int key_lo = (lo + group - 1) / group, key_hi = j / group;
   const int r = t / 7, c = t - 7 * r;
@@ -274,13 +366,25 @@ __global__ __launch_bounds__(64) void k_fused_finish(const int32_t* __restrict__
     const int sj = j - base, sk = k - base;
     const double* pb = kpart + (int64_t)key * stride;
     if (t < 49) {
-      // (Y_j W_k^T)[r][c] = D[8 sk + c][8 sj + r], a lower-triangle tile (sk >= sj)
-      const int ti = sk >> 1, tj = sj >> 1;
-      double v = pb[(ti * (ti + 1) / 2 + tj) * 256 + ((sk & 1) * 8 + c) * 16 + (sj & 1) * 8 + r];
-      if (j == k) v = pb[nt * 256 + sj * kFzSlotRec + uidx] - v;
+      // (Y_j W_k^T)[r][c] = D[7 sk + c][7 sj + r]; D is symmetric and its lower triangle is stored
+      // (a diagonal block takes both of its triangles from the lower one)
+      int row = 7 * sk + c, col = 7 * sj + r;
+      if (col > row) {
+        const int tmp = row;
+        row = col;
+        col = tmp;
+      }
+      double v;
+      if (row < 16 * T) {
+        const int ti = row >> 4, tj = col >> 4;
+        v = pb[(ti * (ti + 1) / 2 + tj) * 256 + (row & 15) * 16 + (col & 15)];
+      } else {
+        v = pb[nt * 256 + (row - 16 * T) * 64 + 8 * (col / 7) + col % 7];
+      }
+      if (j == k) v = pb[nt * 256 + E * 64 + sj * kFzSlotRec + uidx] - v;
       sum += v;
     } else {
-      sum += pb[nt * 256 + sj * kFzSlotRec + 28 + (t - 49)];
+      sum += pb[nt * 256 + E * 64 + sj * kFzSlotRec + 28 + (t - 49)];
     }
   }
   const int64_t ld = 7 * (int64_t)m;
@@ -312,12 +416,27 @@ int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* x
   const int64_t stride = fz_part_stride(p->fz_slots);
   {
     ProfScope ps(KID_FUSED_RUNS, st);
-    if (p->fz_slots == 6)
-      hipLaunchKernelGGL(k_fused_runs<3>, dim3(p->n_runs), dim3(64), 0, st, p->d_run_pt0, p->d_slot_obs, A, xt, xp, mu,
-                         Vinv, eps_b, part);
-    else
-      hipLaunchKernelGGL(k_fused_runs<4>, dim3(p->n_runs), dim3(64), 0, st, p->d_run_pt0, p->d_slot_obs, A, xt, xp, mu,
-                         Vinv, eps_b, part);
+#define FZ_LAUNCH(W, T, E)                                                                                             \
+  do {                                                                                                                 \
+    if (wps == 1)                                                                                                      \
+      hipLaunchKernelGGL((k_fused_runs<W, T, E, 1>), dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0, \
+                         p->d_slot_obs, A, xt, xp, mu, Vinv, eps_b, part);                                            \
+    else                                                                                                               \
+      hipLaunchKernelGGL((k_fused_runs<W, T, E, 2>), dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0, \
+                         p->d_slot_obs, A, xt, xp, mu, Vinv, eps_b, part);                                            \
+  } while (0)
+    static const int wps = [] {
+      const char* v = getenv("SFM_BA_FZ_WPS");
+      return v && v[0] == '1' ? 1 : 2;
+    }();
+    switch (p->fz_slots) {
+      case 4: FZ_LAUNCH(4, 2, 0); break;
+      case 5: FZ_LAUNCH(5, 2, 3); break;
+      case 6: FZ_LAUNCH(6, 3, 0); break;
+      case 7: FZ_LAUNCH(7, 3, 1); break;
+      default: FZ_LAUNCH(8, 4, 0); break;
+    }
+#undef FZ_LAUNCH
   }
   int rc = check_launch_fz("k_fused_runs");
   if (rc) return rc;

@@ -61,7 +61,7 @@ extern "C" void sfm_ba_plan_destroy(sfm_ba_plan* p) {
                   p->d_item_cam, p->d_item_beg, p->d_item_end, p->d_cam_item_ptr, p->d_blk_j, p->d_blk_k,
                   p->d_entries,  p->d_pit_blk,  p->d_pit_beg,  p->d_pit_end, p->d_pit_part, p->d_mb_blk,
                   p->d_mb_part,  p->d_mb_cnt,   p->d_run_pt0,  p->d_run_base, p->d_slot_obs, p->d_key_ptr,
-                  p->d_key_run};
+                  p->d_key_run,  p->d_rng_run};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   delete p;
@@ -249,7 +249,7 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   // first-cameras share a window (key = first camera / group, base camera = key * group); a run is
   // a maximal range of consecutive points with one key, cut at multiples of pmax.  The rule needs
   // no sequential pass either.
-  std::vector<int32_t> run_pt0, run_base, slot_obs, key_ptr, key_run;
+  std::vector<int32_t> run_pt0, run_base, slot_obs, key_ptr, key_run, rng_run;
   {
     int32_t span_max = 0;
     bool empty_point = false;
@@ -279,6 +279,11 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
         p->fz_pmax = sh.pmax;
         p->n_runs = n_runs;
         p->n_keys = (m - 1) / sh.group + 1;
+        // a run starts at every multiple of pmax: ranges of pmax points own whole runs
+        p->n_ranges = (n + sh.pmax - 1) / sh.pmax;
+        rng_run.assign(p->n_ranges + 1, n_runs);
+        for (int32_t r = n_runs - 1; r >= 0; --r)
+          if (run_pt0[r] % sh.pmax == 0) rng_run[run_pt0[r] / sh.pmax] = r;
         slot_obs.assign((size_t)n * kFzLanesPerPoint, -1);
         for (int32_t i = 0; i < n; ++i) {
           const int32_t base = slot_cam[pt_ptr[i]] / sh.group * sh.group;
@@ -331,6 +336,7 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
     up(slot_obs, &p->d_slot_obs);
     up(key_ptr, &p->d_key_ptr);
     up(key_run, &p->d_key_run);
+    up(rng_run, &p->d_rng_run);
   }
   if (rc != SFM_BA_OK) {
     sfm_ba_plan_destroy(p);
@@ -387,6 +393,7 @@ extern "C" int sfm_ba_plan_read(const sfm_ba_plan* p, int field, void* h_dst, in
     case 23: src = p->d_slot_obs; count = p->n_runs > 0 ? (int64_t)p->n * kFzLanesPerPoint : 0; break;
     case 24: src = p->d_key_ptr; count = p->n_runs > 0 ? p->n_keys + 1 : 0; break;
     case 25: src = p->d_key_run; count = p->n_runs; break;
+    case 26: src = p->d_rng_run; count = p->n_runs > 0 ? p->n_ranges + 1 : 0; break;
     default: return SFM_BA_EINVAL;
   }
   *bytes_out = count * width;

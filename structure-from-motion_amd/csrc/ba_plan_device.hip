@@ -298,12 +298,15 @@ __global__ void k_run_flags(const int32_t* __restrict__ pt_ptr, const int32_t* _
 __global__ void k_run_fill(const int32_t* __restrict__ flag, const int32_t* __restrict__ rid,
                            const int32_t* __restrict__ pt_ptr, const int32_t* __restrict__ slot_cam, int32_t n,
                            int32_t group, int32_t* __restrict__ run_pt0, int32_t* __restrict__ run_base,
-                           uint32_t* __restrict__ run_key, int32_t* __restrict__ run_id) {
+                           uint32_t* __restrict__ run_key, int32_t* __restrict__ run_id, int32_t pmax,
+                           int32_t* __restrict__ rng_run) {
   const int32_t i = blockIdx.x * kT + threadIdx.x;
   if (i > n) return;
   if (i == n) {
     run_pt0[rid[n]] = n;  // rid[n] = number of runs
+    rng_run[(n + pmax - 1) / pmax] = rid[n];
   } else if (flag[i]) {
+    if (i % pmax == 0) rng_run[i / pmax] = rid[i];
     const int32_t r = rid[i], key = slot_cam[pt_ptr[i]] / group;
     run_pt0[r] = i;
     run_base[r] = key * group;
@@ -598,8 +601,10 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
       SFMBA_TRY(keep(&p->d_slot_obs, (int64_t)n * kFzLanesPerPoint, &bytes));
       SFMBA_TRY(keep(&p->d_key_ptr, p->n_keys + 1, &bytes));
       SFMBA_TRY(keep(&p->d_key_run, n_runs, &bytes));
+      p->n_ranges = (n + sh.pmax - 1) / sh.pmax;
+      SFMBA_TRY(keep(&p->d_rng_run, p->n_ranges + 1, &bytes));
       k_run_fill<<<blocks_for(n + 1), kT, 0, st>>>(flag, rid, p->d_pt_ptr, p->d_slot_cam, n, sh.group, p->d_run_pt0,
-                                                  p->d_run_base, run_key, run_id);
+                                                  p->d_run_base, run_key, run_id, sh.pmax, p->d_rng_run);
       SFMBA_HIP(hipMemsetAsync(p->d_slot_obs, 0xFF, sizeof(int32_t) * (size_t)n * kFzLanesPerPoint, st));
       k_slot_obs_fill<<<blocks_for(N), kT, 0, st>>>(p->d_pt_ptr, slot_pt, p->d_slot_cam, p->d_perm, N, sh.group,
                                                    p->d_slot_obs);

@@ -43,7 +43,7 @@ class Plan:
 
     FIELDS = ("pt_ptr", "perm", "slot_cam", "tp_ptr", "pair_entry", "grp_pt", "cam_obs", "item_cam", "item_beg",
               "item_end", "cam_item_ptr", "blk_j", "blk_k", "entries", "pit_blk", "pit_beg", "pit_end", "pit_part",
-              "mb_blk", "mb_part", "mb_cnt", "run_pt0", "run_base", "slot_obs", "key_ptr", "key_run")
+              "mb_blk", "mb_part", "mb_cnt", "run_pt0", "run_base", "slot_obs", "key_ptr", "key_run", "rng_run")
 
     def __init__(self, cam_idx, pt_idx, n_cams_hint=0, n_pts_hint=0, check=True, where="device"):
         lib = _lib.load()

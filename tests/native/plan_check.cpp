@@ -120,7 +120,7 @@ int main(int argc, char** argv) {
   // runs of the fused assembly: they tile the points, every observation sits at the slot of its
   // camera in its run's window, every other slot is empty, and the runs are grouped by window
   if (p->n_runs > 0) {
-    REQUIRE(p->fz_slots == 6 || p->fz_slots == 8);
+    REQUIRE(p->fz_slots >= 4 && p->fz_slots <= 8);
     REQUIRE(p->fz_group >= 1 && p->fz_pmax >= 8);
     REQUIRE(p->d_run_pt0[0] == 0 && p->d_run_pt0[p->n_runs] == n);
     std::vector<int64_t> seen_obs((size_t)N, 0);
@@ -137,6 +137,13 @@ int main(int argc, char** argv) {
         }
     }
     for (int64_t o = 0; o < N; ++o) REQUIRE(seen_obs[(size_t)o] == 1);
+    // ranges of pmax points own whole runs
+    REQUIRE(p->n_ranges == (n + p->fz_pmax - 1) / p->fz_pmax);
+    REQUIRE(p->d_rng_run[0] == 0 && p->d_rng_run[p->n_ranges] == p->n_runs);
+    for (int g = 0; g < p->n_ranges; ++g) {
+      REQUIRE(p->d_rng_run[g + 1] > p->d_rng_run[g]);
+      REQUIRE(p->d_run_pt0[p->d_rng_run[g]] == g * p->fz_pmax);
+    }
     REQUIRE(p->n_keys == (m - 1) / p->fz_group + 1);
     REQUIRE(p->d_key_ptr[0] == 0 && p->d_key_ptr[p->n_keys] == p->n_runs);
     std::vector<char> run_hit((size_t)p->n_runs, 0);

@@ -21,11 +21,12 @@ def _problem(m, n, k, seed=0):
 
 # m, n, views per point, cameras per window, first-cameras per window
 CASES = [
-    (30, 6000, (5, 7), 8, 2),
-    (16, 2000, 8, 8, 1),
-    (40, 9000, (3, 5), 6, 2),
-    (25, 4000, 6, 6, 1),
-    (64, 20001, (2, 4), 6, 3),
+    (30, 6000, (5, 7), 7, 1),    # 3 row tiles + 1 extra row
+    (16, 2000, 8, 8, 1),         # 4 row tiles
+    (40, 9000, (3, 5), 5, 1),    # 2 row tiles + 3 extra rows
+    (25, 4000, 6, 6, 1),         # 3 row tiles
+    (64, 20001, (2, 4), 4, 1),   # 2 row tiles
+    (50, 8000, (2, 3), 4, 2),    # two first-cameras per window
 ]
 
 

@@ -24,8 +24,8 @@ def checker(tmp_path_factory):
     (20, 2000, 6, 1, 1, 0),   # banded around a moving centre: first cameras alternate, no runs
     (20, 2000, 6, 2, 1, 1),   # first camera ascends: runs of the fused assembly in windows of 6 cameras
     (60, 30000, 8, 2, 5, 1),  # windows of 8 cameras
-    (90, 30000, 7, 2, 6, 1),  # two first-cameras per window
-    (12, 5000, 5, 2, 7, 1),   # three first-cameras per window of 6
+    (90, 30000, 7, 2, 6, 1),  # windows of 7
+    (12, 5000, 3, 2, 7, 1),   # two first-cameras per window of 4
     (200, 100000, 9, 1, 2),   # split blocks
     (3, 50, 3, 0, 3),
     (40, 400, 30, 0, 4),      # many views per point
