@@ -41,11 +41,14 @@ int main() {
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   const int iters = 200;
-  for (int mode = 0; mode < 4; ++mode) {
-    hipLaunchKernelGGL(k_probe, dim3(256), dim3(512), 0, 0, mode, iters, out);
+  for (int mode = 0; mode < 6; ++mode) {
+    // modes 4, 5: modes 0 and 3 with one wave per SIMD (256 threads)
+    const int threads = mode >= 4 ? 256 : 512;
+    const int kmode = mode == 4 ? 0 : (mode == 5 ? 3 : mode);
+    hipLaunchKernelGGL(k_probe, dim3(256), dim3(threads), 0, 0, kmode, iters, out);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k_probe, dim3(256), dim3(512), 0, 0, mode, iters, out);
+    hipLaunchKernelGGL(k_probe, dim3(256), dim3(threads), 0, 0, kmode, iters, out);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;

@@ -22,6 +22,7 @@ constexpr int kPairPartStride = 56;  // doubles per partial result of a split bl
 // one window of `slots` consecutive camera ids starting at the run's base camera; lane (point, slot)
 // of a wave then owns one observation or none, 8 points per step.
 constexpr int kFzLanesPerPoint = 8;  // lanes (= slot positions of the table) per point
+constexpr int kFzMaxPmax = 1024;     // longest range of points one wave walks (and with it: runs per range)
 constexpr int kFzSlotRec = 40;       // doubles per camera slot behind a partial's tiles: 28 (upper triangle of
                                      // sum A^T A) + 7 (sum A^T g), padded
 struct FzShape {
@@ -36,7 +37,7 @@ inline bool fz_shape(int32_t n, int32_t span_max, bool empty_point, FzShape* o) 
   o->slots = span_max < 4 ? 4 : span_max;
   o->group = o->slots - span_max + 1;
   int pm = ((n + 2047) / 2048 + 7) & ~7;
-  o->pmax = pm < 32 ? 32 : (pm > 1024 ? 1024 : pm);
+  o->pmax = pm < 32 ? 32 : (pm > kFzMaxPmax ? kFzMaxPmax : pm);
   return true;
 }
 // runs must be long enough for their fixed cost (one partial result each) to be small
@@ -110,7 +111,7 @@ struct sfm_ba_plan {
   int32_t* d_key_run = nullptr;   // [n_runs]
   int64_t device_bytes = 0;
   // workspace section offsets (bytes)
-  int64_t ws_g = 0, ws_T = 0, ws_campart = 0, ws_spart = 0, ws_fpart = 0, ws_fkey = 0, ws_total = 0;
+  int64_t ws_g = 0, ws_T = 0, ws_campart = 0, ws_spart = 0, ws_fpart = 0, ws_fkey = 0, ws_fzero = 0, ws_total = 0;
 };
 
 namespace sfmba {

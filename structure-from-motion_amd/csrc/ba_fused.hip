@@ -12,7 +12,8 @@
 // window is as small as the visibility allows (no tile of padding) and the per-point arithmetic
 // avoids divisions.
 //
-// One wave per range of pmax points (a range holds whole runs), no barriers.  Lane (p, s) of a step owns the observation of point p (8 points per
+// One wave per range of pmax points (a range holds whole runs), no barriers; the operand fetches
+// run two steps ahead and do not stop at the end of a run.  Lane (p, s) of a step owns the observation of point p (8 points per
 // step) by the camera at slot s of the window (or none: it then contributes zeros):
 //   1. the row of A, x_true and x_pred come straight into registers (loads for the next step are
 //      issued before the matrix phase of this one);
@@ -24,13 +25,41 @@
 // At the end of the run the wave stores its tiles and per-slot sums as one partial result.  Partials
 // are added in a fixed order (k_fused_reduce: runs of one window; k_fused_finish: windows of one
 // camera pair), so results are reproducible bit for bit.
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "ba_common.h"
 
 namespace sfmba {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// Diagnostic builds (-DSFMBA_FZ_STAMPS) add up, per phase of k_fused_runs, the shader cycles every
+// wave spends there; the launcher prints and clears the sums.  The library build has no stamps.
+#ifdef SFMBA_FZ_STAMPS
+__device__ unsigned long long g_fz_stamps[16];
+#define FZ_STAMP_DECL long long stamp_acc_[16] = {0}, stamp_prev_ = (long long)__builtin_amdgcn_s_memtime()
+#define FZ_STAMP(i)                                                  \
+  do {                                                               \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    const long long now_ = (long long)__builtin_amdgcn_s_memtime();  \
+    stamp_acc_[i] += now_ - stamp_prev_;                             \
+    stamp_prev_ = now_;                                              \
+    __builtin_amdgcn_sched_barrier(0);                               \
+  } while (0)
+#define FZ_STAMP_WAIT(what) asm volatile("s_waitcnt " what ::: "memory")
+#define FZ_STAMP_FLUSH                                                                      \
+  do {                                                                                      \
+    if (threadIdx.x == 0)                                                                   \
+      for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_fz_stamps[i_], (unsigned long long)stamp_acc_[i_]); \
+  } while (0)
+#else
+#define FZ_STAMP_DECL
+#define FZ_STAMP(i)
+#define FZ_STAMP_WAIT(what)
+#define FZ_STAMP_FLUSH
+#endif
 
 __device__ __forceinline__ double2 ldg2(const double* p) { return *reinterpret_cast<const double2*>(p); }
 __device__ __forceinline__ void sts2(double* p, double a, double b) {
@@ -94,7 +123,8 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
     const int32_t* __restrict__ rng_run, const int32_t* __restrict__ run_pt0,
     const int32_t* __restrict__ slot_obs, const double* __restrict__ A,
     const double* __restrict__ xt, const double* __restrict__ xp, double mu, double* __restrict__ Vinv,
-    double* __restrict__ eps_b, double* __restrict__ part) {
+    double* __restrict__ eps_b, double* __restrict__ part, const double* __restrict__ zero_row, int pmax,
+    int n_pts) {
   static_assert(16 * T + E >= 7 * W && 16 * T <= 7 * W + 15, "tiles and extra rows must cover the window");
   static_assert(E == 0 || (16 * T) / 7 == (16 * T + E - 1) / 7, "the extra rows belong to one camera slot");
   static_assert(E == 0 || (16 * T) / 7 == 4 || (16 * T) / 7 == 6, "extra rows are wired for slots 4 and 6");
@@ -102,6 +132,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
   constexpr int NT = T * (T + 1) / 2;
   constexpr int64_t STRIDE = fz_part_stride_c(T, E);
   __shared__ __attribute__((aligned(16))) double Zp[24 * KS];  // [K column = 3 point + q][8 slot + r]
+  __shared__ int bnd[kFzMaxPmax + 1];  // first point of every run of this wave's range, and the range's end
   const int lane = threadIdx.x;
   const int p = lane >> 3, s = lane & 7;
   const int li = lane & 15, lk = lane >> 4;
@@ -112,10 +143,59 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
     const int rho = 16 * t + li;
     roff[t] = rho < 7 * W ? 8 * (rho / 7) + rho % 7 : 7;
   }
-  // a wave walks the runs of one range of points (ranges hold equal numbers of points)
-  const int run_end = rng_run[blockIdx.x + 1];
-  for (int run = rng_run[blockIdx.x]; run < run_end; ++run) {
-  const int pt0 = run_pt0[run], pt1 = run_pt0[run + 1];
+  // A wave walks the runs of one range of pmax points (ranges hold equal numbers of points) as one
+  // stream of steps: a step holds up to 8 consecutive points of one run, and the operands of the
+  // next step - the first step of the next run included - are fetched while this one is worked on.
+  // The boundaries of the range's runs sit in LDS (at most pmax + 1 of them).
+  FZ_STAMP_DECL;
+  const int run0 = rng_run[blockIdx.x];
+  const int nr = rng_run[blockIdx.x + 1] - run0;
+  int f0 = blockIdx.x * pmax, r0 = 0;  // first point of the step, its run (relative to run0)
+  // slot table entry of this lane for a step that starts at point `first` in a run that ends before `lim`
+#define FZ_FETCH_POS(first, lim) (((first) + p) < (lim) ? slot_obs[kFzLanesPerPoint * (int64_t)((first) + p) + s] : -1)
+  // row of A (a_(0..13)), x_true (a_(14..15)) and x_pred (a_(16..17)) of observation `pos`; a lane
+  // without an observation reads the row of zeros the launcher keeps in the workspace (selecting the
+  // address keeps the loads unconditional, so that they land in the registers of av[] themselves)
+#define FZ_FETCH_ROWS(pos)                                                    \
+  do {                                                                        \
+    const bool has_ = (pos) >= 0;                                             \
+    const double* ap_ = has_ ? A + 14 * (int64_t)(pos) : zero_row;            \
+    const double* tp_ = has_ ? xt + 2 * (int64_t)(pos) : zero_row;            \
+    const double* pp_ = has_ ? xp + 2 * (int64_t)(pos) : zero_row;            \
+    _Pragma("unroll") for (int q_ = 0; q_ < 7; ++q_) av[q_] = ldg2(ap_ + 2 * q_); \
+    av[7] = ldg2(tp_);                                                        \
+    av[8] = ldg2(pp_);                                                        \
+  } while (0)
+  // step after the one that starts at `first` in run `r`: 8 points on, or the start of the next run
+#define FZ_ADVANCE(first, r)                                                    \
+  do {                                                                          \
+    (first) += 8;                                                               \
+    if ((first) >= __builtin_amdgcn_readfirstlane(bnd[(r) + 1])) {              \
+      (r) += 1;                                                                 \
+      (first) = __builtin_amdgcn_readfirstlane(bnd[(r)]);                       \
+    }                                                                           \
+  } while (0)
+#define FZ_LIM(r) __builtin_amdgcn_readfirstlane(bnd[(r) + 1])
+  // the first step's table entries do not need the boundaries: they are on their way meanwhile
+  const int pt_first = f0 + p < n_pts ? f0 + p : n_pts - 1;
+  const int pos_raw = slot_obs[kFzLanesPerPoint * (int64_t)pt_first + s];
+  for (int i = lane; i <= nr; i += 64) bnd[i] = run_pt0[run0 + i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // (kept as the 16-byte pieces the loads deliver: the values carried around the loop are then the
+  // load results themselves; as 18 separate doubles they get registers of their own and every step
+  // ends with a wait for the loads and 18 copies)
+  double2 av[9];
+#define a_(i) (((i) & 1) ? av[(i) >> 1].y : av[(i) >> 1].x)
+  int pos = f0 + p < FZ_LIM(0) ? pos_raw : -1;
+  FZ_FETCH_ROWS(pos);
+  int f1 = f0, r1 = r0;
+  FZ_ADVANCE(f1, r1);
+  int pos_next = r1 < nr ? FZ_FETCH_POS(f1, FZ_LIM(r1)) : -1;
+  int f2 = f1, r2 = r1;
+  if (r2 < nr) FZ_ADVANCE(f2, r2);
+  int pos_next2 = r2 < nr ? FZ_FETCH_POS(f2, FZ_LIM(r2)) : -1;
 
   d4_t acc[NT];
 #pragma unroll
@@ -130,39 +210,27 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
 #pragma unroll
     for (int i = 0; i < 7; ++i) xa[e][i] = 0.0;
 
-  // slot table entry of this lane for the step that starts at point `first` (-1: no observation)
-#define FZ_FETCH_POS(first) (((first) + p) < pt1 ? slot_obs[kFzLanesPerPoint * (int64_t)((first) + p) + s] : -1)
-  // row of A (a[0..13]), x_true (a[14..15]) and x_pred (a[16..17]) of observation `pos`, zeros for none
-#define FZ_FETCH_ROWS(pos)                                          \
-  do {                                                              \
-    if ((pos) >= 0) {                                               \
-      const double* ap_ = A + 14 * (int64_t)(pos);                  \
-      _Pragma("unroll") for (int q_ = 0; q_ < 7; ++q_) {            \
-        const double2 v_ = ldg2(ap_ + 2 * q_);                      \
-        a[2 * q_] = v_.x;                                           \
-        a[2 * q_ + 1] = v_.y;                                       \
-      }                                                             \
-      const double2 t_ = ldg2(xt + 2 * (int64_t)(pos));             \
-      const double2 p_ = ldg2(xp + 2 * (int64_t)(pos));             \
-      a[14] = t_.x; a[15] = t_.y; a[16] = p_.x; a[17] = p_.y;       \
-    } else {                                                        \
-      _Pragma("unroll") for (int q_ = 0; q_ < 18; ++q_) a[q_] = 0.0; \
-    }                                                               \
-  } while (0)
-  double a[18];
-  int pos = FZ_FETCH_POS(pt0);
-  int pos_next = FZ_FETCH_POS(pt0 + 8);
-  int pos_next2 = FZ_FETCH_POS(pt0 + 16);
-  FZ_FETCH_ROWS(pos);
+  FZ_STAMP(0);  // set-up
+  while (r0 < nr) {  // runs of the range
+  // steps of the run, as a counted loop of its own: the partial result is written behind it, and
+  // code of that part which the compiler moved into the steps (it does so when the end of a run is
+  // a branch inside one flat loop) makes every step wait for its matrix instructions
+  const int run = run0 + r0;
+  int nsteps = (FZ_LIM(r0) - f0 + 7) >> 3;
+  asm volatile("" : "+s"(nsteps));
+  int step = 0;
+  do {  // (at least one step: the loop's exit then has a block of its own for the copies the write-out needs)
+    const int pt = f0 + p;
+    const int pt1 = FZ_LIM(r0);
+    FZ_STAMP_WAIT("vmcnt(0)");
+    FZ_STAMP(1);  // operands of this step
 
-  for (int first = pt0; first < pt1; first += 8) {
-    const int pt = first + p;
     // ---- per observation: point block and residual.  The point block B is minus the camera-centre
     // columns of A; the arithmetic below works with b = -B (those columns as they are): V = b^T b,
     // q = b^T eps = -eps_b, g = eps + b V^-1 q, and Z comes out with the opposite sign, which Z Z^T
     // does not see ----
-    const double b0 = a[4], b1 = a[5], b2 = a[6], b3 = a[11], b4 = a[12], b5 = a[13];
-    const double e0 = a[14] - a[16], e1 = a[15] - a[17];
+    const double b0 = a_(4), b1 = a_(5), b2 = a_(6), b3 = a_(11), b4 = a_(12), b5 = a_(13);
+    const double e0 = a_(14) - a_(16), e1 = a_(15) - a_(17);
     // B^T B (00 01 02 11 12 22) and B^T eps, summed over the observations of the point
     const double v00 = sum8(b0 * b0 + b3 * b3) + mu;
     const double v01 = sum8(b0 * b1 + b3 * b4);
@@ -176,22 +244,22 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
     // V = C C^T (V is symmetric positive definite for mu > 0), G = C^-1 (lower triangular):
     // V^-1 = G^T G, and Z = W G^T satisfies Z Z^T = W V^-1 W^T.  No division: the reciprocal
     // square roots of the pivots are all that is needed.
-    const double r0 = rsqrt_nr(v00);
-    const double c10 = v01 * r0, c20 = v02 * r0;
+    const double rp0 = rsqrt_nr(v00);
+    const double c10 = v01 * rp0, c20 = v02 * rp0;
     const double d1 = fma(-c10, c10, v11);
-    const double r1 = rsqrt_nr(d1);
-    const double c21 = fma(-c20, c10, v12) * r1;
+    const double rp1 = rsqrt_nr(d1);
+    const double c21 = fma(-c20, c10, v12) * rp1;
     const double d2 = fma(-c21, c21, fma(-c20, c20, v22));
-    const double r2 = rsqrt_nr(d2);
-    const double g10 = -c10 * r0 * r1;
-    const double g21 = -c21 * r1 * r2;
-    const double g20 = -(c20 * r0 + c21 * g10) * r2;
-    const double i00 = fma(g20, g20, fma(g10, g10, r0 * r0));
-    const double i01 = fma(g20, g21, g10 * r1);
-    const double i02 = g20 * r2;
-    const double i11 = fma(g21, g21, r1 * r1);
-    const double i12 = g21 * r2;
-    const double i22 = r2 * r2;
+    const double rp2 = rsqrt_nr(d2);
+    const double g10 = -c10 * rp0 * rp1;
+    const double g21 = -c21 * rp1 * rp2;
+    const double g20 = -(c20 * rp0 + c21 * g10) * rp2;
+    const double i00 = fma(g20, g20, fma(g10, g10, rp0 * rp0));
+    const double i01 = fma(g20, g21, g10 * rp1);
+    const double i02 = g20 * rp2;
+    const double i11 = fma(g21, g21, rp1 * rp1);
+    const double i12 = g21 * rp2;
+    const double i22 = rp2 * rp2;
     if (pt < pt1) {
       // lane s < 3 of the point stores row s of V^-1 and entry s of eps_b.  Three masked blocks on
       // laundered copies of s: a selection by s (of values or of addresses) is turned into a table
@@ -212,8 +280,8 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
     const double g0 = e0 - (b0 * z0 + b1 * z1 + b2 * z2);  // (-B)(-V^-1 eps_b) = B V^-1 eps_b
     const double g1 = e1 - (b3 * z0 + b4 * z1 + b5 * z2);
     // ---- B G^T (2 x 3): column q is sum_{a <= q} B[:, a] G[q][a]; then Z = A^T (B G^T) ----
-    const double m00 = b0 * r0, m01 = fma(b1, r1, b0 * g10), m02 = fma(b2, r2, fma(b1, g21, b0 * g20));
-    const double m10 = b3 * r0, m11 = fma(b4, r1, b3 * g10), m12 = fma(b5, r2, fma(b4, g21, b3 * g20));
+    const double m00 = b0 * rp0, m01 = fma(b1, rp1, b0 * g10), m02 = fma(b2, rp2, fma(b1, g21, b0 * g20));
+    const double m10 = b3 * rp0, m11 = fma(b4, rp1, b3 * g10), m12 = fma(b5, rp2, fma(b4, g21, b3 * g20));
     __builtin_amdgcn_sched_barrier(0);  // (phases kept apart: interleaving them costs registers)
     // ---- per camera slot: U_j += A^T A, e_j += A^T g ----
     {
@@ -221,8 +289,8 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
 #pragma unroll
       for (int r = 0; r < 7; ++r) {
 #pragma unroll
-        for (int c = r; c < 7; ++c, ++v) u[v] = fma(a[7 + r], a[7 + c], fma(a[r], a[c], u[v]));
-        ev[r] = fma(a[7 + r], g1, fma(a[r], g0, ev[r]));
+        for (int c = r; c < 7; ++c, ++v) u[v] = fma(a_(7 + r), a_(7 + c), fma(a_(r), a_(c), u[v]));
+        ev[r] = fma(a_(7 + r), g1, fma(a_(r), g0, ev[r]));
       }
     }
     // ---- rows behind the tiles: D[x][7 s + r] += sum_q Z_x[q] Z_s[r][q] with Z_s[r][q] = A_s[:, r] . M_s[:, q]
@@ -233,9 +301,9 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
       constexpr int dummy = 16 * T;
       const int rho = dummy + e;
       const int rx = rho % 7;
-      const double w0 = fma(a[7 + rx], m10, a[rx] * m00);
-      const double w1 = fma(a[7 + rx], m11, a[rx] * m01);
-      const double w2 = fma(a[7 + rx], m12, a[rx] * m02);
+      const double w0 = fma(a_(7 + rx), m10, a_(rx) * m00);
+      const double w1 = fma(a_(7 + rx), m11, a_(rx) * m01);
+      const double w2 = fma(a_(7 + rx), m12, a_(rx) * m02);
       double x0, x1, x2;
       if ((dummy + e) / 7 == 4) {
         x0 = bcast8<4>(w0, s); x1 = bcast8<4>(w1, s); x2 = bcast8<4>(w2, s);
@@ -245,9 +313,10 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
       const double h0 = fma(x2, m02, fma(x1, m01, x0 * m00));
       const double h1 = fma(x2, m12, fma(x1, m11, x0 * m10));
 #pragma unroll
-      for (int r = 0; r < 7; ++r) xa[e][r] = fma(a[7 + r], h1, fma(a[r], h0, xa[e][r]));
+      for (int r = 0; r < 7; ++r) xa[e][r] = fma(a_(7 + r), h1, fma(a_(r), h0, xa[e][r]));
     }
     __builtin_amdgcn_sched_barrier(0);
+    FZ_STAMP(2);  // per-point phase, U, e, rows behind the tiles
     // ---- Z into the panel (slots at and beyond W never hold an observation: their lanes write the
     // zeros that the operand reads of rows past the window pick up at offset 7) ----
     {
@@ -258,7 +327,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
         const double mb = q == 0 ? m10 : (q == 1 ? m11 : m12);
         double z[7];
 #pragma unroll
-        for (int r = 0; r < 7; ++r) z[r] = fma(a[7 + r], mb, a[r] * ma);
+        for (int r = 0; r < 7; ++r) z[r] = fma(a_(7 + r), mb, a_(r) * ma);
         sts2(zp + q * KS, z[0], z[1]);
         sts2(zp + q * KS + 2, z[2], z[3]);
         sts2(zp + q * KS + 4, z[4], z[5]);
@@ -270,10 +339,22 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- next step's operands on their way while the matrix cores work ----
+    FZ_STAMP(3);  // Z and its stores
+    FZ_STAMP_WAIT("lgkmcnt(0)");
+    FZ_STAMP(4);  // panel landed
+    f0 = f1; r0 = r1;
+    // (the fetch overwrites av[]: it must stay below the last use of the old values, or the new ones
+    // get registers of their own and every step ends with a wait for the loads and 14 copies.  Loads
+    // are not tied to a scheduling barrier when the instructions are selected; a memory clobber is.)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     pos = pos_next;
     FZ_FETCH_ROWS(pos);
+    f1 = f2; r1 = r2;
     pos_next = pos_next2;
-    pos_next2 = FZ_FETCH_POS(first + 24);
+    if (r2 < nr) FZ_ADVANCE(f2, r2);
+    pos_next2 = r2 < nr ? FZ_FETCH_POS(f2, FZ_LIM(r2)) : -1;
+    FZ_STAMP(5);  // fetches of the next step issued
 #pragma unroll
     for (int kk = 0; kk < 6; ++kk) {
       double zt[T];
@@ -288,35 +369,67 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    FZ_STAMP(6);  // matrix phase issued
+  } while (++step < nsteps);
+    {
+      // ---- the run's partial result: tiles as they lie in the registers, the extra rows, the per-slot
+      // sums; then everything starts from zero for the next run ----
+      double* po = part + (int64_t)run * STRIDE;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) po[t * 256 + (lk + 4 * v) * 16 + li] = acc[t][v];
+        acc[t] = d4_t{0.0, 0.0, 0.0, 0.0};
+      }
+      // the per-slot sums (28 + 7 + 7 E values per lane) are added over the 8 points through the
+      // panel's LDS, 21 values at a time: lane l parks value j at [j][l], then lane (j, slot) adds the
+      // eight entries [j][8 p + slot] in the order of p and stores the sum
+      constexpr int NV = 35 + 7 * E;
+#pragma unroll
+      for (int c0 = 0; c0 < NV; c0 += 21) {
+        const int cnt = NV - c0 < 21 ? NV - c0 : 21;
+#pragma unroll
+        for (int j = 0; j < 21; ++j) {
+          const int i = c0 + j;
+          if (i < NV) Zp[j * 64 + lane] = i < 28 ? u[i < 28 ? i : 0] : (i < 35 ? ev[i < 35 && i >= 28 ? i - 28 : 0] : xa[i >= 35 ? (i - 35) / 7 : 0][i >= 35 ? (i - 35) % 7 : 0]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int o = 64 * k + lane;
+          if (o < 8 * cnt) {
+            const int j = o >> 3, ss = o & 7, i = c0 + j;
+            const double* z = Zp + j * 64 + ss;
+            double sum = z[0];
+#pragma unroll
+            for (int pp = 1; pp < 8; ++pp) sum += z[8 * pp];
+            const int dst = i < 35 ? NT * 256 + E * 64 + ss * kFzSlotRec + i
+                                   : NT * 256 + ((i - 35) / 7) * 64 + 8 * ss + (i - 35) % 7;
+            po[dst] = sum;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+#pragma unroll
+      for (int i = 0; i < 28; ++i) u[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) ev[i] = 0.0;
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) xa[e][i] = 0.0;
+      FZ_STAMP(7);  // partial result of a run
+    }
   }
+  FZ_STAMP_FLUSH;
 #undef FZ_FETCH_POS
 #undef FZ_FETCH_ROWS
-
-  // ---- the run's partial result: tiles as they lie in the registers, the extra rows, the per-slot sums ----
-  double* po = part + (int64_t)run * STRIDE;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) po[t * 256 + (lk + 4 * v) * 16 + li] = acc[t][v];
-#pragma unroll
-  for (int e = 0; e < E; ++e)
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const double v = sum_over_points(xa[e][i]);
-      if (p == 0) po[NT * 256 + e * 64 + 8 * s + i] = v;
-    }
-  double* uo = po + NT * 256 + E * 64 + s * kFzSlotRec;
-#pragma unroll
-  for (int i = 0; i < 28; ++i) {
-    const double v = sum_over_points(u[i]);
-    if (p == 0) uo[i] = v;
-  }
-#pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const double v = sum_over_points(ev[i]);
-    if (p == 0) uo[28 + i] = v;
-  }
-  }  // runs of the range
+#undef FZ_ADVANCE
+#undef FZ_LIM
+#undef a_
 }
 
 // partial results of the runs of one window, added in run order
@@ -414,16 +527,19 @@ int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* x
   double* part = reinterpret_cast<double*>(base + p->ws_fpart);
   double* kpart = reinterpret_cast<double*>(base + p->ws_fkey);
   const int64_t stride = fz_part_stride(p->fz_slots);
+  // lanes of k_fused_runs without an observation read their operands from here
+  const double* zero_row = reinterpret_cast<const double*>(base + p->ws_fzero);
+  SFMBA_HIP(hipMemsetAsync(base + p->ws_fzero, 0, 256, st));
   {
     ProfScope ps(KID_FUSED_RUNS, st);
 #define FZ_LAUNCH(W, T, E)                                                                                             \
   do {                                                                                                                 \
     if (wps == 1)                                                                                                      \
       hipLaunchKernelGGL((k_fused_runs<W, T, E, 1>), dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0, \
-                         p->d_slot_obs, A, xt, xp, mu, Vinv, eps_b, part);                                            \
+                         p->d_slot_obs, A, xt, xp, mu, Vinv, eps_b, part, zero_row, p->fz_pmax, p->n);                                            \
     else                                                                                                               \
       hipLaunchKernelGGL((k_fused_runs<W, T, E, 2>), dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0, \
-                         p->d_slot_obs, A, xt, xp, mu, Vinv, eps_b, part);                                            \
+                         p->d_slot_obs, A, xt, xp, mu, Vinv, eps_b, part, zero_row, p->fz_pmax, p->n);                                            \
   } while (0)
     static const int wps = [] {
       const char* v = getenv("SFM_BA_FZ_WPS");
@@ -438,6 +554,16 @@ int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* x
     }
 #undef FZ_LAUNCH
   }
+#ifdef SFMBA_FZ_STAMPS
+  {
+    unsigned long long h[16];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fz_stamps), sizeof(h));
+    fprintf(stderr, "fz stamps (previous launch): setup %llu operands %llu valu %llu z %llu panel %llu fetch %llu mfma %llu flush %llu\n",
+            h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    memset(h, 0, sizeof(h));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fz_stamps), h, sizeof(h));
+  }
+#endif
   int rc = check_launch_fz("k_fused_runs");
   if (rc) return rc;
   if (!S) return SFM_BA_OK;

@@ -46,6 +46,8 @@ void plan_set_workspace(sfm_ba_plan* p) {
   off = align256(off + (int64_t)p->n_runs * fz_part_stride(p->fz_slots) * (int64_t)sizeof(double));
   p->ws_fkey = off;
   off = align256(off + (int64_t)p->n_keys * fz_part_stride(p->fz_slots) * (int64_t)sizeof(double));
+  p->ws_fzero = off;  // a row of zeros
+  off = align256(off + 256);
   p->ws_total = off;
 }
 

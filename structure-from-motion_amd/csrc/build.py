@@ -22,6 +22,7 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-x", "hip",
            "-Wall", "-Wno-unused-result"]
+    cmd += os.environ.get("SFM_BA_EXTRA_FLAGS", "").split()  # diagnostic builds, e.g. -DSFMBA_FZ_STAMPS
     cmd += [os.path.join(HERE, s) for s in SOURCES]
     cmd += ["-o", LIB]
     if verbose:
