@@ -282,6 +282,19 @@ int sfm_ba_cost(const sfm_ba_plan* plan, const double* d_P, const double* d_X, c
                 const int32_t* d_pt_idx, const double* d_x_true, double* d_cam_ssq, double* d_cost,
                 void* d_workspace, void* stream);
 
+/* The same cost (d_cam_ssq [m], d_cost[0], bit for bit what sfm_ba_cost writes) for callers that cannot
+ * allocate or hand over a workspace: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  No counterpart in the reference.  The per-item partial sums go to a device
+ * array that is part of the library (512 KiB on every GPU the library runs on, kept until the process
+ * ends), and the call performs no allocation of any kind (no timing events either: it is never part
+ * of the per-kernel profile).  Limit: SFM_BA_COST_NOALLOC_MAX_ITEMS per-camera work items, i.e. sum over
+ * cameras of ceil(observations of the camera / 1024); a larger plan is refused with SFM_BA_ETOOBIG.
+ * All calls on one GPU share the array: calls that overlap on one GPU (different streams) race. */
+#define SFM_BA_COST_NOALLOC_MAX_ITEMS 65536
+int sfm_ba_cost_noalloc(const sfm_ba_plan* plan, const double* d_P, const double* d_X, const int32_t* d_cam_idx,
+                        const int32_t* d_pt_idx, const double* d_x_true, double* d_cam_ssq, double* d_cost,
+                        void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Two-view linear triangulation: the step that produces the points bundle adjustment starts from.
  * Work of `triangulate_pts` (src/triangulation.py:10-32): per correspondence the null direction of

@@ -60,6 +60,7 @@ SYMBOLS = {
                                              _vp]),
     "sfm_ba_cost": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_ba_cost_finish": (_int, [_vp, _i32, _vp, _vp]),
+    "sfm_ba_cost_noalloc": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_ba_profile_enable": (_int, [_int]),
     "sfm_ba_profile_select": (_int, [C.c_uint64]),
     "sfm_ba_profile_kernel_count": (_int, []),

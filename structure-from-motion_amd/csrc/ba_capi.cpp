@@ -168,6 +168,14 @@ int sfm_ba_cost(const sfm_ba_plan* plan, const double* d_P, const double* d_X, c
                      static_cast<hipStream_t>(stream));
 }
 
+int sfm_ba_cost_noalloc(const sfm_ba_plan* plan, const double* d_P, const double* d_X, const int32_t* d_cam_idx,
+                        const int32_t* d_pt_idx, const double* d_x_true, double* d_cam_ssq, double* d_cost,
+                        void* stream) {
+  if (!plan || !d_P || !d_X || !d_cam_idx || !d_pt_idx || !d_x_true || !d_cam_ssq || !d_cost) return SFM_BA_EINVAL;
+  return launch_cost_noalloc(plan, d_P, d_X, d_cam_idx, d_pt_idx, d_x_true, d_cam_ssq, d_cost,
+                             static_cast<hipStream_t>(stream));
+}
+
 int sfm_ba_cost_partial(const sfm_ba_plan* plan, const double* d_P, const double* d_X, const int32_t* d_cam_idx,
                         const int32_t* d_pt_idx, const double* d_x_true, double* d_cam_ssq, void* d_workspace,
                         void* stream) {

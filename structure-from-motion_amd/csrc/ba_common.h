@@ -176,6 +176,8 @@ int launch_cost(const sfm_ba_plan* p, const double* P, const double* X, const in
 int launch_cost_partial(const sfm_ba_plan* p, const double* P, const double* X, const int32_t* cam,
                         const int32_t* pt, const double* xt, double* ssq, void* ws, hipStream_t st);
 int launch_cost_finish(const double* ssq, int m, double* cost, hipStream_t st);
+int launch_cost_noalloc(const sfm_ba_plan* p, const double* P, const double* X, const int32_t* cam, const int32_t* pt,
+                        const double* xt, double* ssq, double* cost, hipStream_t st);
 int64_t cholesky_workspace_bytes(int n7);
 // half_bandwidth < 0: dense; otherwise S[r][c] = 0 wherever |r - c| > half_bandwidth
 int launch_solve_reduced(double* S, int n7, int half_bandwidth, double* da, void* ws, int32_t* info, hipStream_t st);

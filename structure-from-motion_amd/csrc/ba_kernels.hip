@@ -9,6 +9,8 @@
 //   S          dense (7m+1) x 7m row-major; row 7m carries the right-hand side e
 //
 // Every reduction runs in a fixed order (no atomics), so results are reproducible bit for bit.
+#include <mutex>
+
 #include "ba_common.h"
 
 namespace sfmba {
@@ -1212,6 +1214,49 @@ int launch_cost(const sfm_ba_plan* p, const double* P, const double* X, const in
     ProfScope ps(KID_COST_FINISH, st);
     hipLaunchKernelGGL(k_cost_sum_finish, dim3(1), dim3(256), 0, st, p->d_cam_item_ptr, campart, p->m, ssq, cost);
   }
+  return check_launch("k_cost_sum_finish");
+}
+
+// ------------------------------------------------------------------------------------------
+// cost without any allocation: the per-item partial sums live in a file-scope device array instead
+// of the caller's workspace.  Every GPU holds its own copy of the array at its own address; the
+// address is looked up once per device (the array's name is only a host-side handle: handed to a
+// kernel as it stands it is not a device address).
+// ------------------------------------------------------------------------------------------
+constexpr int kCostStaticItems = 65536;  // per-camera work items (of <= 1024 observations) the array holds
+static __device__ __align__(256) double g_cost_scratch[kCostStaticItems];
+constexpr int kMaxDevices = 64;
+static double* g_cost_scratch_ptr[kMaxDevices];  // per device, null until looked up
+static std::mutex g_cost_scratch_mu;
+
+static int cost_scratch_for_current_device(double** out) {
+  int dev = -1;
+  SFMBA_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return SFM_BA_EINVAL;
+  std::lock_guard<std::mutex> lk(g_cost_scratch_mu);
+  if (!g_cost_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    SFMBA_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_cost_scratch)));
+    g_cost_scratch_ptr[dev] = static_cast<double*>(ptr);
+  }
+  *out = g_cost_scratch_ptr[dev];
+  return SFM_BA_OK;
+}
+
+int launch_cost_noalloc(const sfm_ba_plan* p, const double* P, const double* X, const int32_t* cam, const int32_t* pt,
+                        const double* xt, double* ssq, double* cost, hipStream_t st) {
+  if (p->n_items > kCostStaticItems) return SFM_BA_ETOOBIG;
+  double* campart = nullptr;
+  const int rc0 = cost_scratch_for_current_device(&campart);
+  if (rc0) return rc0;
+  // (no timing scopes here: they create events)
+  if (p->n_items > 0) {
+    hipLaunchKernelGGL(k_cost_items, dim3(p->n_items), dim3(kCamThreads), 0, st, p->d_item_beg, p->d_item_end,
+                       p->d_cam_obs, P, X, cam, pt, xt, campart);
+    const int rc = check_launch("k_cost_items");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_cost_sum_finish, dim3(1), dim3(256), 0, st, p->d_cam_item_ptr, campart, p->m, ssq, cost);
   return check_launch("k_cost_sum_finish");
 }
 
