@@ -254,7 +254,8 @@ def main():
     del full
     prob = DeviceProblem(prob_h.K, prob_h.R, prob_h.T, prob_h.X, prob_h.cam_idx, prob_h.pt_idx, prob_h.x_true,
                          n_cams=m, group=group, check=(world == 1),
-                         plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"))
+                         plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"),
+                         steps=bool(int(os.environ.get("SFM_BA_STEPS", "0"))))
     N_loc, n_loc = prob.N, prob.n
 
     def barrier():

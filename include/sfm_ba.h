@@ -87,10 +87,10 @@ void sfm_ba_plan_destroy(sfm_ba_plan* plan);
  * 2 slot_cam, 3 tp_ptr, 4 pair_entry, 5 grp_pt, 6 cam_obs (empty when the caller order is
  * camera-sorted), 7-9 per-camera items (camera, begin, end), 10 cam_item_ptr, 11-12 block cameras
  * (j, k), 13 pair entries (two uint32 each), 14-17 pair items (block, begin, end, partial), 18-20
- * split blocks (block, first partial, partials), 21-26 runs of the fused assembly (first point of
+ * split blocks (block, first partial, partials), 21-29 runs of the fused assembly (first point of
  * each run, base camera, observation per (point, window slot), runs grouped by window: row pointer
- * and run ids, first run of every range of points that one wave walks; all empty when the plan has
- * no runs).  *bytes receives the array's size; h_dst may be
+ * and run ids, first run of every range of points that one wave walks, first point and run of every
+ * step of 8 points, first step of every range; all empty when the plan has no runs).  *bytes receives the array's size; h_dst may be
  * null to query it, otherwise `capacity` must be at least that size. */
 int sfm_ba_plan_read(const sfm_ba_plan* plan, int field, void* h_dst, int64_t capacity, int64_t* bytes);
 /* sizes: what[0]=n_cams, [1]=n_pts, [2]=n_obs, [3]=number of camera-pair blocks (j<=k) with a shared
@@ -109,10 +109,11 @@ int32_t sfm_ba_plan_half_bandwidth(const sfm_ba_plan* plan);
  * d_cam_red, with mu > 0 - then forms V^-1, eps_b, S and e in a single pass over d_A.
  *   info[0] = 1 when that path will be taken, [1] = cameras per window (0: pattern not eligible),
  *   [2] = first-cameras that share a window, [3] = largest run length in points, [4] = runs,
- *   [5] = windows.  sfm_ba_plan_set_fused(plan, 0) turns the path off for this plan (tests compare
+ *   [5] = windows, [6] = steps (groups of up to 8 consecutive points of one run), [7] = ranges of
+ *   points (one wave each).  sfm_ba_plan_set_fused(plan, 0) turns the path off for this plan (tests compare
  *   the two paths); both give the same S and e to rounding.  No counterpart in the reference, whose
  *   calc_S (src/sparse_ba.py:237-258) walks camera pairs. */
-int sfm_ba_plan_fused_info(const sfm_ba_plan* plan, int32_t info[6]);
+int sfm_ba_plan_fused_info(const sfm_ba_plan* plan, int32_t info[8]);
 int sfm_ba_plan_set_fused(sfm_ba_plan* plan, int enable);
 /* bytes of the scratch workspace the assemble / back-substitution entry points need */
 int64_t sfm_ba_plan_workspace_bytes(const sfm_ba_plan* plan);
@@ -177,6 +178,29 @@ int sfm_ba_schur_assemble(const sfm_ba_plan* plan, const double* d_A, const doub
                           double mu, double mu_u, double* d_S, double* d_e, double* d_U,
                           double* d_eps_a, double* d_V_inv, double* d_eps_b, double* d_cam_red,
                           void* d_workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The same three stages on "step blocks", for plans with runs (sfm_ba_plan_fused_info): the layout
+ * the loop uses when nobody needs A in the reference's [N,2,7] form.  A step is up to 8 consecutive
+ * points of one run; its block holds, for every (point, camera slot of the run's window), the row
+ * of A and the residual x_true - x_pred as 8 pieces of 16 bytes (zeros where the point has no
+ * observation by that camera), piece-major, so that a wave reads or writes a block as 8 contiguous
+ * KiB.  d_steps: sfm_ba_plan_steps_elements(plan) doubles (8 KiB per step).
+ *   sfm_ba_jacobian_steps        : compute_A_B + the projection of get_indices
+ *                                  (src/bundle_adjustment.py:22-67, src/jacobian.py:21-220) into d_steps
+ *   sfm_ba_schur_assemble_steps  : calc_V_inv ... calc_e (src/sparse_ba.py:147-271) from d_steps; mu > 0;
+ *                                  d_S (lower triangle), d_e, d_V_inv, d_eps_b as sfm_ba_schur_assemble
+ *                                  writes them without by-products
+ *   sfm_ba_back_substitute_steps : calc_delta_b (src/sparse_ba.py:279-290) and the point update
+ * ---------------------------------------------------------------------------------------- */
+int64_t sfm_ba_plan_steps_elements(const sfm_ba_plan* plan);
+int sfm_ba_jacobian_steps(const sfm_ba_plan* plan, const double* d_cam_blk, const double* d_P, const double* d_X,
+                          const double* d_x_true, double* d_steps, void* stream);
+int sfm_ba_schur_assemble_steps(const sfm_ba_plan* plan, const double* d_steps, double mu, double mu_u, double* d_S,
+                                double* d_e, double* d_V_inv, double* d_eps_b, void* d_workspace, void* stream);
+int sfm_ba_back_substitute_steps(const sfm_ba_plan* plan, const double* d_steps, const double* d_V_inv,
+                                 const double* d_eps_b, const double* d_delta_a, double* d_delta_b, double* d_X_update,
+                                 double x_step, void* stream);
 
 /* W [N,7,3] and Y [N,7,3] as the reference materialises them (calc_W, calc_Y,
  * src/sparse_ba.py:215-234).  Not needed by the solve; provided for callers that inspect them. */

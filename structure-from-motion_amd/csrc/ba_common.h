@@ -102,10 +102,14 @@ struct sfm_ba_plan {
   int32_t* d_mb_cnt = nullptr;    // number of partials
   // fused point-major assembly (fz_slots = 0: the visibility pattern does not allow it)
   int32_t fz_slots = 0, fz_group = 0, fz_pmax = 0, fz_enabled = 1;
-  int32_t n_runs = 0, n_keys = 0, n_ranges = 0;
+  int32_t n_runs = 0, n_keys = 0, n_ranges = 0, n_steps = 0;
   int32_t* d_run_pt0 = nullptr;   // [n_runs+1] first point of each run
   int32_t* d_run_base = nullptr;  // [n_runs] first camera of the run's window
   int32_t* d_rng_run = nullptr;   // [n_ranges+1] first run of every range of fz_pmax points (one wave per range)
+  // steps: up to 8 consecutive points of one run; the steps of a run, of a range and of the plan are consecutive
+  int32_t* d_step_pt0 = nullptr;  // [n_steps] first point of the step
+  int32_t* d_step_run = nullptr;  // [n_steps + 1] its run (entry n_steps: n_runs)
+  int32_t* d_rng_step = nullptr;  // [n_ranges+1] first step of every range
   int32_t* d_slot_obs = nullptr;  // [n][8] observation (caller order) of point i at camera base + slot, or -1
   int32_t* d_key_ptr = nullptr;   // [n_keys+1] runs grouped by window (key = base / group), ascending run id
   int32_t* d_key_run = nullptr;   // [n_runs]
@@ -160,8 +164,14 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
                     double* U, double* eps_a, double* Vinv, double* eps_b, double* cam_red,
                     void* ws, hipStream_t st);
 // the fused path of launch_assemble (plan with runs, no weights, no by-products, B taken from A)
-int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* xt, const double* xp, double mu,
-                          double mu_u, double* S, double* e, double* Vinv, double* eps_b, void* ws, hipStream_t st);
+// (steps: the step blocks of launch_jacobian_steps, or null to gather the operands from A, xt, xp)
+int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* xt, const double* xp,
+                          const double* steps, double mu, double mu_u, double* S, double* e, double* Vinv,
+                          double* eps_b, void* ws, hipStream_t st);
+int launch_jacobian_steps(const sfm_ba_plan* p, const double* blk, const double* P, const double* X, const double* xt,
+                          double* steps, hipStream_t st);
+int launch_back_substitute_steps(const sfm_ba_plan* p, const double* steps, const double* Vinv, const double* eps_b,
+                                 const double* da, double* db, double* Xupd, double x_step, hipStream_t st);
 int launch_calc_W_Y(const sfm_ba_plan* p, const double* A, const double* B, const double* w,
                     const double* Vinv, const int32_t* pt, double* W, double* Y, hipStream_t st);
 int launch_add_diagonal(double* S, int n7, double mu, hipStream_t st);

@@ -118,11 +118,16 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 // themselves (21 FMAs per row and step: cheaper than another row of tiles for E <= 3).
 //   W = 4: T 2, E 0 (28 rows)   W = 5: T 2, E 3 (35)   W = 6: T 3, E 0 (42)   W = 7: T 3, E 1 (49)
 //   W = 8: T 4, E 0 (56)
-template <int W, int T, int E, int WPS>  // WPS: waves per SIMD the register allocation leaves room for
+// BLOCKED: the operands come from the step blocks k_jacobian_steps wrote (block k = step k of the
+// plan: 8 pieces of 1 KiB, piece q holding 16 bytes per lane: the row of A in pieces 0..6, the
+// residual x_true - x_pred in piece 7), every load a whole contiguous KiB; otherwise they are
+// gathered row by row from A, x_true and x_pred in the caller's order through the slot table.
+template <int W, int T, int E, int WPS, bool BLOCKED>  // WPS: waves per SIMD the register allocation leaves room for
 __global__ __launch_bounds__(64, WPS) void k_fused_runs(
     const int32_t* __restrict__ rng_run, const int32_t* __restrict__ run_pt0,
     const int32_t* __restrict__ slot_obs, const double* __restrict__ A,
-    const double* __restrict__ xt, const double* __restrict__ xp, double mu, double* __restrict__ Vinv,
+    const double* __restrict__ xt, const double* __restrict__ xp, const int32_t* __restrict__ rng_step,
+    const double2* __restrict__ Ab, double mu, double* __restrict__ Vinv,
     double* __restrict__ eps_b, double* __restrict__ part, const double* __restrict__ zero_row, int pmax,
     int n_pts) {
   static_assert(16 * T + E >= 7 * W && 16 * T <= 7 * W + 15, "tiles and extra rows must cover the window");
@@ -158,6 +163,11 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
   // address keeps the loads unconditional, so that they land in the registers of av[] themselves)
 #define FZ_FETCH_ROWS(pos)                                                    \
   do {                                                                        \
+    if (BLOCKED) {                                                            \
+      const double2* bp_ = Ab + (int64_t)kfetch * 512 + lane;                 \
+      _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) av[q_] = bp_[64 * q_]; \
+      break;                                                                  \
+    }                                                                         \
     const bool has_ = (pos) >= 0;                                             \
     const double* ap_ = has_ ? A + 14 * (int64_t)(pos) : zero_row;            \
     const double* tp_ = has_ ? xt + 2 * (int64_t)(pos) : zero_row;            \
@@ -178,7 +188,8 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
 #define FZ_LIM(r) __builtin_amdgcn_readfirstlane(bnd[(r) + 1])
   // the first step's table entries do not need the boundaries: they are on their way meanwhile
   const int pt_first = f0 + p < n_pts ? f0 + p : n_pts - 1;
-  const int pos_raw = slot_obs[kFzLanesPerPoint * (int64_t)pt_first + s];
+  const int pos_raw = BLOCKED ? 0 : slot_obs[kFzLanesPerPoint * (int64_t)pt_first + s];
+  int kfetch = BLOCKED ? rng_step[blockIdx.x] : 0;  // step whose block the next fetch reads
   for (int i = lane; i <= nr; i += 64) bnd[i] = run_pt0[run0 + i];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -192,10 +203,10 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
   FZ_FETCH_ROWS(pos);
   int f1 = f0, r1 = r0;
   FZ_ADVANCE(f1, r1);
-  int pos_next = r1 < nr ? FZ_FETCH_POS(f1, FZ_LIM(r1)) : -1;
+  int pos_next = !BLOCKED && r1 < nr ? FZ_FETCH_POS(f1, FZ_LIM(r1)) : -1;
   int f2 = f1, r2 = r1;
   if (r2 < nr) FZ_ADVANCE(f2, r2);
-  int pos_next2 = r2 < nr ? FZ_FETCH_POS(f2, FZ_LIM(r2)) : -1;
+  int pos_next2 = !BLOCKED && r2 < nr ? FZ_FETCH_POS(f2, FZ_LIM(r2)) : -1;
 
   d4_t acc[NT];
 #pragma unroll
@@ -230,7 +241,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
     // q = b^T eps = -eps_b, g = eps + b V^-1 q, and Z comes out with the opposite sign, which Z Z^T
     // does not see ----
     const double b0 = a_(4), b1 = a_(5), b2 = a_(6), b3 = a_(11), b4 = a_(12), b5 = a_(13);
-    const double e0 = a_(14) - a_(16), e1 = a_(15) - a_(17);
+    const double e0 = BLOCKED ? a_(14) : a_(14) - a_(16), e1 = BLOCKED ? a_(15) : a_(15) - a_(17);
     // B^T B (00 01 02 11 12 22) and B^T eps, summed over the observations of the point
     const double v00 = sum8(b0 * b0 + b3 * b3) + mu;
     const double v01 = sum8(b0 * b1 + b3 * b4);
@@ -349,11 +360,12 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     pos = pos_next;
+    if (BLOCKED && r0 < nr) ++kfetch;  // (behind the last step of the range: its own block once more)
     FZ_FETCH_ROWS(pos);
     f1 = f2; r1 = r2;
     pos_next = pos_next2;
     if (r2 < nr) FZ_ADVANCE(f2, r2);
-    pos_next2 = r2 < nr ? FZ_FETCH_POS(f2, FZ_LIM(r2)) : -1;
+    pos_next2 = !BLOCKED && r2 < nr ? FZ_FETCH_POS(f2, FZ_LIM(r2)) : -1;
     FZ_STAMP(5);  // fetches of the next step issued
 #pragma unroll
     for (int kk = 0; kk < 6; ++kk) {
@@ -511,6 +523,65 @@ __global__ __launch_bounds__(64) void k_fused_finish(const int32_t* __restrict__
   }
 }
 
+// Back-substitution on the step blocks (src/sparse_ba.py:279-290): lane (p, s) of a step holds the
+// row of A of point p's observation by the window's camera s (zeros for none);
+// delta_b_i = V_i^-1 (eps_b_i - sum_s B_s^T A_s delta_a[cam_s]) with B = minus the camera-centre columns of A.
+__global__ __launch_bounds__(256) void k_back_substitute_steps(
+    int n_steps, const int32_t* __restrict__ step_pt0, const int32_t* __restrict__ step_run,
+    const int32_t* __restrict__ run_pt0, const int32_t* __restrict__ run_base, const double2* __restrict__ Ab,
+    const double* __restrict__ Vinv, const double* __restrict__ eps_b, const double* __restrict__ da,
+    double* __restrict__ db, double* __restrict__ Xupd, double x_step, int m) {
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= n_steps) return;
+  const int lane = threadIdx.x & 63, p = lane >> 3, s = lane & 7;
+  const int run = step_run[k];
+  const int pt = step_pt0[k] + p, lim = run_pt0[run + 1];
+  int cam = run_base[run] + s;
+  cam = cam < m ? cam : m - 1;  // (a slot past the last camera holds no observation: its row is zero)
+  const double2* bp = Ab + (int64_t)k * 512 + lane;
+  double a[14];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const double2 v = bp[64 * q];
+    a[2 * q] = v.x;
+    a[2 * q + 1] = v.y;
+  }
+  // delta_a of the window's 8 cameras (56 contiguous doubles) through LDS: one load per lane
+  __shared__ double sDa[4][56];
+  {
+    const int base = run_base[run];
+    const int nd = (m - base < 8 ? m - base : 8) * 7;
+    if (lane < nd) sDa[threadIdx.x >> 6][lane] = da[7 * (int64_t)base + lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  const double* dj = sDa[threadIdx.x >> 6] + 7 * (cam - run_base[run]);
+  double h0 = 0.0, h1 = 0.0;
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    h0 += a[q] * dj[q];
+    h1 += a[7 + q] * dj[q];
+  }
+  const double c0 = sum8(-a[4] * h0 - a[11] * h1);
+  const double c1 = sum8(-a[5] * h0 - a[12] * h1);
+  const double c2 = sum8(-a[6] * h0 - a[13] * h1);
+  if (s == 0 && pt < lim) {
+    const double r0 = eps_b[3 * (int64_t)pt] - c0, r1 = eps_b[3 * (int64_t)pt + 1] - c1,
+                 r2 = eps_b[3 * (int64_t)pt + 2] - c2;
+    const double* v = Vinv + 9 * (int64_t)pt;
+    const double d0 = v[0] * r0 + v[1] * r1 + v[2] * r2;
+    const double d1 = v[3] * r0 + v[4] * r1 + v[5] * r2;
+    const double d2 = v[6] * r0 + v[7] * r1 + v[8] * r2;
+    db[3 * (int64_t)pt] = d0; db[3 * (int64_t)pt + 1] = d1; db[3 * (int64_t)pt + 2] = d2;
+    if (Xupd) {
+      Xupd[3 * (int64_t)pt] += x_step * d0;
+      Xupd[3 * (int64_t)pt + 1] += x_step * d1;
+      Xupd[3 * (int64_t)pt + 2] += x_step * d2;
+    }
+  }
+}
+
 static inline int check_launch_fz(const char* what) {
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) {
@@ -520,8 +591,9 @@ static inline int check_launch_fz(const char* what) {
   return SFM_BA_OK;
 }
 
-int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* xt, const double* xp, double mu,
-                          double mu_u, double* S, double* e, double* Vinv, double* eps_b, void* ws, hipStream_t st) {
+int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* xt, const double* xp,
+                          const double* steps, double mu, double mu_u, double* S, double* e, double* Vinv,
+                          double* eps_b, void* ws, hipStream_t st) {
   if (p->n_runs <= 0) return SFM_BA_OK;
   char* base = static_cast<char*>(ws);
   double* part = reinterpret_cast<double*>(base + p->ws_fpart);
@@ -532,14 +604,23 @@ int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* x
   SFMBA_HIP(hipMemsetAsync(base + p->ws_fzero, 0, 256, st));
   {
     ProfScope ps(KID_FUSED_RUNS, st);
-#define FZ_LAUNCH(W, T, E)                                                                                             \
-  do {                                                                                                                 \
-    if (wps == 1)                                                                                                      \
-      hipLaunchKernelGGL((k_fused_runs<W, T, E, 1>), dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0, \
-                         p->d_slot_obs, A, xt, xp, mu, Vinv, eps_b, part, zero_row, p->fz_pmax, p->n);                                            \
-    else                                                                                                               \
-      hipLaunchKernelGGL((k_fused_runs<W, T, E, 2>), dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0, \
-                         p->d_slot_obs, A, xt, xp, mu, Vinv, eps_b, part, zero_row, p->fz_pmax, p->n);                                            \
+#define FZ_LAUNCH4(W, T, E, WPS, BL)                                                                             \
+  hipLaunchKernelGGL((k_fused_runs<W, T, E, WPS, BL>), dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0, \
+                     p->d_slot_obs, A, xt, xp, p->d_rng_step, reinterpret_cast<const double2*>(steps), mu, Vinv,    \
+                     eps_b, part, zero_row, p->fz_pmax, p->n)
+#define FZ_LAUNCH(W, T, E)                    \
+  do {                                        \
+    if (steps) {                              \
+      if (wps == 1)                           \
+        FZ_LAUNCH4(W, T, E, 1, true);         \
+      else                                    \
+        FZ_LAUNCH4(W, T, E, 2, true);         \
+    } else {                                  \
+      if (wps == 1)                           \
+        FZ_LAUNCH4(W, T, E, 1, false);        \
+      else                                    \
+        FZ_LAUNCH4(W, T, E, 2, false);        \
+    }                                         \
   } while (0)
     static const int wps = [] {
       const char* v = getenv("SFM_BA_FZ_WPS");
@@ -553,6 +634,7 @@ int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* x
       default: FZ_LAUNCH(8, 4, 0); break;
     }
 #undef FZ_LAUNCH
+#undef FZ_LAUNCH4
   }
 #ifdef SFMBA_FZ_STAMPS
   {
@@ -580,6 +662,18 @@ int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* x
                        p->fz_slots, p->fz_group, kpart, mu_u, p->m, S, e);
   }
   return check_launch_fz("k_fused_finish");
+}
+
+int launch_back_substitute_steps(const sfm_ba_plan* p, const double* steps, const double* Vinv, const double* eps_b,
+                                 const double* da, double* db, double* Xupd, double x_step, hipStream_t st) {
+  if (p->n_steps <= 0) return SFM_BA_OK;
+  {
+    ProfScope ps(KID_BACK, st);
+    hipLaunchKernelGGL(k_back_substitute_steps, dim3((p->n_steps + 3) / 4), dim3(256), 0, st, p->n_steps, p->d_step_pt0,
+                       p->d_step_run, p->d_run_pt0, p->d_run_base, reinterpret_cast<const double2*>(steps), Vinv, eps_b,
+                       da, db, Xupd, x_step, p->m);
+  }
+  return check_launch_fz("k_back_substitute_steps");
 }
 
 }  // namespace sfmba

@@ -257,6 +257,67 @@ __global__ __launch_bounds__(256) void k_jacobian(
   }
 }
 
+// The same Jacobian rows and the residual, written as step blocks for the fused assembly and the
+// back-substitution on steps: block k (8 KiB) = step k of the plan, piece q (1 KiB) = 16 bytes per
+// lane (p, s) = (point of the step, camera slot of the run's window): pieces 0..6 the row of A
+// ([dF/dQ | dF/dC] of the x pixel, then of the y pixel), piece 7 x_true - x_pred; zeros where the
+// point has no observation by that camera.  Every store is a whole contiguous KiB.
+__global__ __launch_bounds__(256) void k_jacobian_steps(
+    int n_steps, const int32_t* __restrict__ step_pt0, const int32_t* __restrict__ step_run,
+    const int32_t* __restrict__ run_pt0, const int32_t* __restrict__ run_base,
+    const int32_t* __restrict__ slot_obs, const double* __restrict__ blk, const double* __restrict__ P,
+    const double* __restrict__ X, const double* __restrict__ xt, double2* __restrict__ Ab, int m) {
+  // per wave: the prepared records (56 doubles) and projection matrices (12) of the 8 cameras of the
+  // step's window, copied once from their contiguous range; the lanes then read their camera's from LDS
+  __shared__ __attribute__((aligned(16))) double sRec[4][8 * (SFM_BA_CAM_BLK + 12)];
+  const int wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * 4 + wave;
+  if (k >= n_steps) return;
+  const int lane = threadIdx.x & 63, p = lane >> 3, s = lane & 7;
+  const int run = step_run[k];
+  const int base = run_base[run];
+  const int pt = step_pt0[k] + p;
+  const int pos = pt < run_pt0[run + 1] ? slot_obs[kFzLanesPerPoint * (int64_t)pt + s] : -1;
+  double* rec = sRec[wave];
+  {
+    const int ncam = m - base < 8 ? m - base : 8;  // cameras of the window that exist
+    const double2* src = reinterpret_cast<const double2*>(blk + (int64_t)SFM_BA_CAM_BLK * base);
+    double2* dst = reinterpret_cast<double2*>(rec);
+    for (int i = lane; i < ncam * (SFM_BA_CAM_BLK / 2); i += 64) dst[i] = src[i];
+    const double2* srcp = reinterpret_cast<const double2*>(P + 12 * (int64_t)base);
+    double2* dstp = reinterpret_cast<double2*>(rec + 8 * SFM_BA_CAM_BLK);
+    for (int i = lane; i < ncam * 6; i += 64) dstp[i] = srcp[i];
+  }
+  // one wave wrote and reads: its LDS operations complete in order
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  double2 out[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) out[q] = make_double2(0.0, 0.0);
+  if (pos >= 0) {
+    const double x0 = X[3 * (int64_t)pt], x1 = X[3 * (int64_t)pt + 1], x2 = X[3 * (int64_t)pt + 2];
+    JacOut o;
+    jacobian_rows(rec + SFM_BA_CAM_BLK * s, x0, x1, x2, o);
+    const double* pm = rec + 8 * SFM_BA_CAM_BLK + 12 * s;
+    const double h0 = pm[0] * x0 + pm[1] * x1 + pm[2] * x2 + pm[3];
+    const double h1 = pm[4] * x0 + pm[5] * x1 + pm[6] * x2 + pm[7];
+    const double h2 = pm[8] * x0 + pm[9] * x1 + pm[10] * x2 + pm[11];
+    const double2 xo = ld2(xt + 2 * (int64_t)pos);
+    out[0] = make_double2(o.a0[0], o.a0[1]);
+    out[1] = make_double2(o.a0[2], o.a0[3]);
+    out[2] = make_double2(-o.b0[0], -o.b0[1]);
+    out[3] = make_double2(-o.b0[2], o.a1[0]);
+    out[4] = make_double2(o.a1[1], o.a1[2]);
+    out[5] = make_double2(o.a1[3], -o.b1[0]);
+    out[6] = make_double2(-o.b1[1], -o.b1[2]);
+    out[7] = make_double2(xo.x - h0 / h2, xo.y - h1 / h2);
+  }
+  double2* bp = Ab + (int64_t)k * 512 + lane;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) bp[64 * q] = out[q];
+}
+
 // ------------------------------------------------------------------------------------------
 // per-point stage: V_i, V_i^-1, eps_b_i, then per observation g = w (eps - B V^-1 eps_b) and per
 // observation pair (a <= b) of the point the 2x2 coupling T_ab = (wB)_a V^-1 (wB)_b^T.
@@ -1050,6 +1111,18 @@ int launch_jacobian(const double* blk, const double* P, const double* X, const i
   return check_launch("k_jacobian");
 }
 
+int launch_jacobian_steps(const sfm_ba_plan* p, const double* blk, const double* P, const double* X, const double* xt,
+                          double* steps, hipStream_t st) {
+  if (p->n_steps <= 0) return SFM_BA_OK;
+  {
+    ProfScope ps(KID_JACOBIAN, st);
+    hipLaunchKernelGGL(k_jacobian_steps, dim3((p->n_steps + 3) / 4), dim3(256), 0, st, p->n_steps, p->d_step_pt0,
+                       p->d_step_run, p->d_run_pt0, p->d_run_base, p->d_slot_obs, blk, P, X, xt,
+                       reinterpret_cast<double2*>(steps), p->m);
+  }
+  return check_launch("k_jacobian_steps");
+}
+
 int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, const double* xt,
                     const double* xp, const double* w, double mu, double mu_u, double* S, double* e,
                     double* U, double* eps_a, double* Vinv, double* eps_b, double* cam_red,
@@ -1065,7 +1138,7 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
   // ... and, where the plan found runs of points inside narrow camera windows, the whole assembly
   // is one pass over A (ba_fused.hip).  That path takes the point block from A and needs mu > 0.
   if (fold_u && !B && !w && mu > 0.0 && p->n_runs > 0 && p->fz_enabled)
-    return launch_assemble_fused(p, A, xt, xp, mu, mu_u, S, e, Vinv, eps_b, ws, st);
+    return launch_assemble_fused(p, A, xt, xp, nullptr, mu, mu_u, S, e, Vinv, eps_b, ws, st);
   if (p->n_groups > 0) {
     {
     ProfScope ps(KID_POINT, st);

@@ -63,7 +63,7 @@ extern "C" void sfm_ba_plan_destroy(sfm_ba_plan* p) {
                   p->d_item_cam, p->d_item_beg, p->d_item_end, p->d_cam_item_ptr, p->d_blk_j, p->d_blk_k,
                   p->d_entries,  p->d_pit_blk,  p->d_pit_beg,  p->d_pit_end, p->d_pit_part, p->d_mb_blk,
                   p->d_mb_part,  p->d_mb_cnt,   p->d_run_pt0,  p->d_run_base, p->d_slot_obs, p->d_key_ptr,
-                  p->d_key_run,  p->d_rng_run};
+                  p->d_key_run,  p->d_rng_run,  p->d_step_pt0, p->d_step_run, p->d_rng_step};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   delete p;
@@ -251,7 +251,7 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   // first-cameras share a window (key = first camera / group, base camera = key * group); a run is
   // a maximal range of consecutive points with one key, cut at multiples of pmax.  The rule needs
   // no sequential pass either.
-  std::vector<int32_t> run_pt0, run_base, slot_obs, key_ptr, key_run, rng_run;
+  std::vector<int32_t> run_pt0, run_base, slot_obs, key_ptr, key_run, rng_run, step_pt0, step_run, rng_step;
   {
     int32_t span_max = 0;
     bool empty_point = false;
@@ -286,6 +286,20 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
         rng_run.assign(p->n_ranges + 1, n_runs);
         for (int32_t r = n_runs - 1; r >= 0; --r)
           if (run_pt0[r] % sh.pmax == 0) rng_run[run_pt0[r] / sh.pmax] = r;
+        // steps of 8 points, run by run
+        std::vector<int32_t> run_step0(n_runs + 1, 0);
+        for (int32_t r = 0; r < n_runs; ++r) {
+          run_step0[r] = (int32_t)step_pt0.size();
+          for (int32_t f = run_pt0[r]; f < run_pt0[r + 1]; f += 8) {
+            step_pt0.push_back(f);
+            step_run.push_back(r);
+          }
+        }
+        run_step0[n_runs] = (int32_t)step_pt0.size();
+        p->n_steps = (int32_t)step_pt0.size();
+        step_run.push_back(n_runs);
+        rng_step.resize(p->n_ranges + 1);
+        for (int32_t g = 0; g <= p->n_ranges; ++g) rng_step[g] = run_step0[rng_run[g]];
         slot_obs.assign((size_t)n * kFzLanesPerPoint, -1);
         for (int32_t i = 0; i < n; ++i) {
           const int32_t base = slot_cam[pt_ptr[i]] / sh.group * sh.group;
@@ -339,6 +353,9 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
     up(key_ptr, &p->d_key_ptr);
     up(key_run, &p->d_key_run);
     up(rng_run, &p->d_rng_run);
+    up(step_pt0, &p->d_step_pt0);
+    up(step_run, &p->d_step_run);
+    up(rng_step, &p->d_rng_step);
   }
   if (rc != SFM_BA_OK) {
     sfm_ba_plan_destroy(p);
@@ -396,6 +413,9 @@ extern "C" int sfm_ba_plan_read(const sfm_ba_plan* p, int field, void* h_dst, in
     case 24: src = p->d_key_ptr; count = p->n_runs > 0 ? p->n_keys + 1 : 0; break;
     case 25: src = p->d_key_run; count = p->n_runs; break;
     case 26: src = p->d_rng_run; count = p->n_runs > 0 ? p->n_ranges + 1 : 0; break;
+    case 27: src = p->d_step_pt0; count = p->n_steps; break;
+    case 28: src = p->d_step_run; count = p->n_runs > 0 ? p->n_steps + 1 : 0; break;
+    case 29: src = p->d_rng_step; count = p->n_runs > 0 ? p->n_ranges + 1 : 0; break;
     default: return SFM_BA_EINVAL;
   }
   *bytes_out = count * width;
@@ -411,7 +431,7 @@ extern "C" int32_t sfm_ba_plan_half_bandwidth(const sfm_ba_plan* p) {
   return p ? 7 * p->max_cam_dist + 6 : -1;
 }
 
-extern "C" int sfm_ba_plan_fused_info(const sfm_ba_plan* p, int32_t info[6]) {
+extern "C" int sfm_ba_plan_fused_info(const sfm_ba_plan* p, int32_t info[8]) {
   if (!p || !info) return SFM_BA_EINVAL;
   info[0] = p->n_runs > 0 && p->fz_enabled ? 1 : 0;
   info[1] = p->fz_slots;
@@ -419,6 +439,8 @@ extern "C" int sfm_ba_plan_fused_info(const sfm_ba_plan* p, int32_t info[6]) {
   info[3] = p->fz_pmax;
   info[4] = p->n_runs;
   info[5] = p->n_keys;
+  info[6] = p->n_steps;
+  info[7] = p->n_ranges;
   return SFM_BA_OK;
 }
 

@@ -315,6 +315,34 @@ __global__ void k_run_fill(const int32_t* __restrict__ flag, const int32_t* __re
   }
 }
 
+// steps of 8 points: per run its number of steps (element n_runs: 0, for the prefix sum), then the steps
+__global__ void k_run_step_counts(const int32_t* __restrict__ run_pt0, int32_t n_runs, int32_t* __restrict__ cnt) {
+  const int32_t r = blockIdx.x * kT + threadIdx.x;
+  if (r > n_runs) return;
+  cnt[r] = r < n_runs ? (run_pt0[r + 1] - run_pt0[r] + 7) / 8 : 0;
+}
+
+__global__ void k_step_fill(const int32_t* __restrict__ run_pt0, const int32_t* __restrict__ run_step0, int32_t n_runs,
+                            int32_t* __restrict__ step_pt0, int32_t* __restrict__ step_run) {
+  const int32_t r = blockIdx.x * kT + threadIdx.x;
+  if (r > n_runs) return;
+  if (r == n_runs) {
+    step_run[run_step0[n_runs]] = n_runs;
+    return;
+  }
+  int32_t k = run_step0[r];
+  for (int32_t f = run_pt0[r]; f < run_pt0[r + 1]; f += 8, ++k) {
+    step_pt0[k] = f;
+    step_run[k] = r;
+  }
+}
+
+__global__ void k_range_steps(const int32_t* __restrict__ rng_run, const int32_t* __restrict__ run_step0, int32_t n_ranges,
+                              int32_t* __restrict__ rng_step) {
+  const int32_t g = blockIdx.x * kT + threadIdx.x;
+  if (g <= n_ranges) rng_step[g] = run_step0[rng_run[g]];
+}
+
 // observation of every (point, window slot)
 __global__ void k_slot_obs_fill(const int32_t* __restrict__ pt_ptr, const int32_t* __restrict__ slot_pt,
                                 const int32_t* __restrict__ slot_cam, const int32_t* __restrict__ perm, int64_t N,
@@ -608,6 +636,22 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
       SFMBA_HIP(hipMemsetAsync(p->d_slot_obs, 0xFF, sizeof(int32_t) * (size_t)n * kFzLanesPerPoint, st));
       k_slot_obs_fill<<<blocks_for(N), kT, 0, st>>>(p->d_pt_ptr, slot_pt, p->d_slot_cam, p->d_perm, N, sh.group,
                                                    p->d_slot_obs);
+      {
+        int32_t *step_cnt, *run_step0;
+        SFMBA_HIP(scratch.get(&step_cnt, n_runs + 1));
+        SFMBA_HIP(scratch.get(&run_step0, n_runs + 1));
+        k_run_step_counts<<<blocks_for(n_runs + 1), kT, 0, st>>>(p->d_run_pt0, n_runs, step_cnt);
+        SFMBA_TRY(scan_exclusive(step_cnt, run_step0, n_runs + 1, scratch, st));
+        int32_t n_steps = 0;
+        SFMBA_HIP(hipMemcpyAsync(&n_steps, run_step0 + n_runs, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        SFMBA_HIP(hipStreamSynchronize(st));
+        p->n_steps = n_steps;
+        SFMBA_TRY(keep(&p->d_step_pt0, n_steps, &bytes));
+        SFMBA_TRY(keep(&p->d_step_run, n_steps + 1, &bytes));
+        SFMBA_TRY(keep(&p->d_rng_step, p->n_ranges + 1, &bytes));
+        k_step_fill<<<blocks_for(n_runs + 1), kT, 0, st>>>(p->d_run_pt0, run_step0, n_runs, p->d_step_pt0, p->d_step_run);
+        k_range_steps<<<blocks_for(p->n_ranges + 1), kT, 0, st>>>(p->d_rng_run, run_step0, p->n_ranges, p->d_rng_step);
+      }
       SFMBA_TRY(sort_pairs(run_key, run_key_sorted, run_id, p->d_key_run, n_runs, bits_for(p->n_keys), scratch, st));
       k_key_ptr<<<blocks_for(p->n_keys + 1), kT, 0, st>>>(run_key_sorted, n_runs, p->n_keys, p->d_key_ptr);
     }

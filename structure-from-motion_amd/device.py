@@ -43,7 +43,7 @@ class Plan:
 
     FIELDS = ("pt_ptr", "perm", "slot_cam", "tp_ptr", "pair_entry", "grp_pt", "cam_obs", "item_cam", "item_beg",
               "item_end", "cam_item_ptr", "blk_j", "blk_k", "entries", "pit_blk", "pit_beg", "pit_end", "pit_part",
-              "mb_blk", "mb_part", "mb_cnt", "run_pt0", "run_base", "slot_obs", "key_ptr", "key_run", "rng_run")
+              "mb_blk", "mb_part", "mb_cnt", "run_pt0", "run_base", "slot_obs", "key_ptr", "key_run", "rng_run", "step_pt0", "step_run", "rng_step")
 
     def __init__(self, cam_idx, pt_idx, n_cams_hint=0, n_pts_hint=0, check=True, where="device"):
         lib = _lib.load()
@@ -79,10 +79,11 @@ class Plan:
          self.n_items, self.device_bytes) = [int(v) for v in sizes]
         self.workspace_bytes = int(lib.sfm_ba_plan_workspace_bytes(handle))
         self.half_bandwidth = int(lib.sfm_ba_plan_half_bandwidth(handle))
-        info = (C.c_int32 * 6)()
+        info = (C.c_int32 * 8)()
         _lib.check(lib.sfm_ba_plan_fused_info(handle, info))
         # runs of the fused point-major assembly (0 runs: the visibility pattern does not allow it)
-        (self.fused, self.fused_slots, self.fused_group, self.fused_pmax, self.n_runs, self.n_keys) = [int(v) for v in info]
+        (self.fused, self.fused_slots, self.fused_group, self.fused_pmax, self.n_runs, self.n_keys, self.n_steps,
+         self.n_ranges) = [int(v) for v in info]
 
     def set_fused(self, enable):
         """Turn the fused point-major assembly of this plan on or off (on by default where runs exist)."""
@@ -122,9 +123,14 @@ class DeviceProblem:
     X_STEP = 0.5   # :100
 
     def __init__(self, K, R, T, X, cam_idx, pt_idx, x_true, n_cams=None, group=None, check=True, device=None,
-                 sharded=None, plan_where="device"):
+                 sharded=None, plan_where="device", steps=False):
         self.lib = _lib.load()
         self.device = _dev(device)
+        # steps: keep the rows of A as step blocks (plans with runs only).  The assembly kernel then
+        # reads whole contiguous KiB, but the blocks carry the empty (point, camera slot) lanes along,
+        # and the Jacobian and back-substitution kernels lose more than the assembly gains (measured
+        # on 500 cameras x 300 000 points: 0.495 ms per iteration against 0.476 ms): off by default.
+        self.use_steps = bool(steps)
         self.group = group
         self.world = 1
         if group is not None:
@@ -239,6 +245,9 @@ class DeviceProblem:
             self.compact = torch.empty((int(self.lib.sfm_ba_band_compact_elements(n7, self.half_bandwidth)),),
                                        dtype=F64, device=d)
         self.cost_buf = torch.zeros((1,), dtype=F64, device=d)
+        # step blocks: rows of A and residuals in the order the fused assembly walks them (plans with runs)
+        n_el = int(self.lib.sfm_ba_plan_steps_elements(self.plan.handle)) if self.use_steps else 0
+        self.steps = torch.empty((n_el,), dtype=F64, device=d) if n_el > 0 else None
 
     # -- single stages ---------------------------------------------------------------------
     def camera_prepare(self):
@@ -255,13 +264,20 @@ class DeviceProblem:
                                             self.N, p(self.A), p(self.B) if want_B else None,
                                             p(self.x_pred) if want_pred else None, _stream()))
 
+    def jacobian_steps(self):
+        """Rows of A and residuals as step blocks (plans with runs): what ``assemble(steps=True)`` and
+        ``back_substitute(steps=True)`` read instead of A, x_true and x_pred."""
+        p = _lib.ptr
+        _lib.check(self.lib.sfm_ba_jacobian_steps(self.plan.handle, p(self.cam_blk), p(self.P), p(self.X),
+                                                  p(self.x_true), p(self.steps), _stream()))
+
     def predict(self):
         p = _lib.ptr
         _lib.check(self.lib.sfm_ba_jacobian(p(self.cam_blk), p(self.P), p(self.X), p(self.cam_idx), p(self.pt_idx),
                                             self.N, None, None, p(self.x_pred), _stream()))
 
     def assemble(self, mu, weights=None, x_true=None, x_pred=None, A=None, B=None, by_products=True,
-                 reduce_packed=False):
+                 reduce_packed=False, steps=False):
         """``by_products=False`` skips U and eps_a (the solve needs only S and e): the library then
         folds the per-camera sums into the camera-pair kernel and makes one pass less over A."""
         p = _lib.ptr
@@ -283,12 +299,18 @@ class DeviceProblem:
             # all-reduce of a sharded run left the other ranks' blocks there
             # (row n7, the right-hand side, included: a shard need not observe every camera)
             self.sys[: (n7 + 1) * n7].zero_()
-        _lib.check(self.lib.sfm_ba_schur_assemble(
-            self.plan.handle, p(self.A if A is None else A), None if B is False else p(self.B if B is None else B),
-            p(self.x_true if x_true is None else x_true), p(self.x_pred if x_pred is None else x_pred),
-            p(weights), float(mu), float(mu_u), p(self.S), p(self.e), p(self.U) if by_products else None,
-            p(self.eps_a) if by_products else None,
-            p(self.V_inv), p(self.eps_b), None, p(self.workspace), _stream()))
+        if steps:
+            _lib.check(self.lib.sfm_ba_schur_assemble_steps(
+                self.plan.handle, p(self.steps), float(mu), float(mu_u), p(self.S), p(self.e), p(self.V_inv),
+                p(self.eps_b), p(self.workspace), _stream()))
+        else:
+            _lib.check(self.lib.sfm_ba_schur_assemble(
+                self.plan.handle, p(self.A if A is None else A),
+                None if B is False else p(self.B if B is None else B),
+                p(self.x_true if x_true is None else x_true), p(self.x_pred if x_pred is None else x_pred),
+                p(weights), float(mu), float(mu_u), p(self.S), p(self.e), p(self.U) if by_products else None,
+                p(self.eps_a) if by_products else None,
+                p(self.V_inv), p(self.eps_b), None, p(self.workspace), _stream()))
         if reduce_packed:
             import torch.distributed as dist
 
@@ -314,8 +336,13 @@ class DeviceProblem:
         _lib.check(self.lib.sfm_ba_solve_reduced_banded(p(self.S), self.n7, self.half_bandwidth, p(self.delta_a),
                                                         p(self.chol_ws), p(self.info), _stream()))
 
-    def back_substitute(self, weights=None, update_points=False, A=None, B=None):
+    def back_substitute(self, weights=None, update_points=False, A=None, B=None, steps=False):
         p = _lib.ptr
+        if steps:
+            _lib.check(self.lib.sfm_ba_back_substitute_steps(
+                self.plan.handle, p(self.steps), p(self.V_inv), p(self.eps_b), p(self.delta_a), p(self.delta_b),
+                p(self.X) if update_points else None, float(self.X_STEP), _stream()))
+            return
         _lib.check(self.lib.sfm_ba_back_substitute(
             self.plan.handle, p(self.A if A is None else A), None if B is False else p(self.B if B is None else B),
             p(weights), p(self.V_inv), p(self.eps_b), p(self.delta_a), p(self.delta_b),
@@ -362,10 +389,17 @@ class DeviceProblem:
         mu = self.MU if mu is None else mu
         if not self._blk_fresh:
             self.camera_prepare()
-        self.jacobian(want_B=False)
-        self.assemble(mu, by_products=False, reduce_packed=True, B=False)
-        self.solve()
-        self.back_substitute(update_points=True, B=False)
+        if self.plan.fused and self.steps is not None and mu > 0:
+            # plans with runs: A and the residuals never exist in the caller's order
+            self.jacobian_steps()
+            self.assemble(mu, reduce_packed=True, steps=True)
+            self.solve()
+            self.back_substitute(update_points=True, steps=True)
+        else:
+            self.jacobian(want_B=False)
+            self.assemble(mu, by_products=False, reduce_packed=True, B=False)
+            self.solve()
+            self.back_substitute(update_points=True, B=False)
         self.update_cameras(prepare_next=True)
         self.cost_async()
 

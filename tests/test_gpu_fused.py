@@ -41,7 +41,7 @@ def test_fused_matches_pair_path(m, n, k, slots, group):
     dev = Plan(p.cam_idx, p.pt_idx, where="device")
     assert host.fused == dev.fused == 1
     assert (dev.fused_slots, dev.fused_group) == (slots, group)
-    for f in ("run_pt0", "run_base", "slot_obs", "key_ptr", "key_run"):
+    for f in ("run_pt0", "run_base", "slot_obs", "key_ptr", "key_run", "rng_run", "step_pt0", "step_run", "rng_step"):
         a, b = host.read(f), dev.read(f)
         assert a.shape == b.shape and np.array_equal(a, b), f
     assert host.workspace_bytes == dev.workspace_bytes
@@ -53,7 +53,7 @@ def test_fused_matches_pair_path(m, n, k, slots, group):
     assert np.array_equal(np.sort(obs), np.arange(p.n_obs))
     assert np.array_equal(p.pt_idx[obs], pts) and np.array_equal(p.cam_idx[obs], base[pts] + sl)
 
-    prob = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true)
+    prob = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true, steps=True)
     assert prob.plan.fused == 1
     prob.camera_prepare()
     prob.jacobian(want_B=False)
@@ -78,6 +78,41 @@ def test_fused_matches_pair_path(m, n, k, slots, group):
     prob.assemble(MU, by_products=False, B=False)
     assert bool((torch.tril(prob.S[:n7]) == res[1][0]).all().item()) and bool((prob.S[n7] == res[1][1]).all().item())
 
+    # the same stages on step blocks (rows of A and residuals in the order the kernel walks them):
+    # the blocks hold exactly the rows of A and x_true - x_pred, the assembly gives the same sums
+    # bit for bit (same arithmetic, other addresses), the back-substitution the same update to rounding
+    assert dev.n_steps > 0 and prob.steps is not None and prob.steps.numel() == 1024 * dev.n_steps
+    prob.jacobian(want_B=False)
+    prob.steps.fill_(float("nan"))
+    prob.jacobian_steps()
+    blocks = prob.steps.view(dev.n_steps, 8, 64, 2).cpu().numpy()
+    step_pt0, step_run, run_pt0 = dev.read("step_pt0"), dev.read("step_run"), dev.read("run_pt0")
+    A_h = prob.A.cpu().numpy()
+    eps_h = p.x_true - prob.x_pred.cpu().numpy()
+    rows = blocks[:, :7].transpose(0, 2, 1, 3).reshape(dev.n_steps, 64, 14)   # [step][lane][14]
+    eps_b = blocks[:, 7]                                                       # [step][lane][2]
+    pt_of = step_pt0[:, None] + (np.arange(64) >> 3)[None, :]
+    valid = pt_of < run_pt0[step_run[:-1] + 1][:, None]
+    obs_of = np.where(valid, so[np.minimum(pt_of, n - 1), (np.arange(64) & 7)[None, :]], -1)
+    has = obs_of >= 0
+    assert np.array_equal(rows[has], A_h[obs_of[has]])
+    assert np.max(np.abs(eps_b[has] - eps_h[obs_of[has]])) <= 1e-12 * np.max(np.abs(eps_h))
+    assert not rows[~has].any() and not eps_b[~has].any()
+    assert int(has.sum()) == p.n_obs
+    prob.sys.zero_()
+    prob.V_inv.fill_(float("nan"))
+    prob.eps_b.fill_(float("nan"))
+    prob.assemble(MU, steps=True)
+    got = [torch.tril(prob.S[:n7]).clone(), prob.S[n7].clone(), prob.e.clone(), prob.V_inv.clone(), prob.eps_b.clone()]
+    for name, a, b in zip(("S", "e (row 7m)", "e", "V_inv", "eps_b"), res[1], got):
+        scale = float(a.abs().max().item())
+        assert float((a - b).abs().max().item()) <= 1e-13 * scale, name
+    prob.solve()
+    prob.back_substitute(B=False)
+    db_rows = prob.delta_b.clone()
+    prob.back_substitute(steps=True)
+    assert float((db_rows - prob.delta_b).abs().max().item()) <= 1e-12 * float(db_rows.abs().max().item())
+
 
 @pytest.mark.parametrize("m,n,k", [(30, 6000, (5, 7)), (40, 9000, (3, 5))])
 def test_fused_iteration_against_oracle(m, n, k):
@@ -93,8 +128,8 @@ def test_fused_iteration_against_oracle(m, n, k):
     R, T, X = p.R.copy(), p.T.copy(), p.X.copy()
     ref = [orc.gn_iteration_arrays(p.K, R, T, X, p.cam_idx, p.pt_idx, p.x_true) for _ in range(2)]
     costs = {}
-    for fused in (1, 0):
-        prob = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true)
+    for fused in (1, 0, 2):  # 2: the fused assembly on step blocks
+        prob = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true, steps=(fused == 2))
         assert prob.plan.fused == 1
         prob.plan.set_fused(fused)
         costs[fused] = []
@@ -109,8 +144,8 @@ def test_fused_iteration_against_oracle(m, n, k):
             assert relerr(prob.delta_a.cpu().numpy(), da_ref) < 1e-7
             assert relerr(prob.delta_b.cpu().numpy(), db_ref) < 1e-7
         assert relerr(prob.points(), X) < 1e-8
-    for a, b in zip(costs[0], costs[1]):
-        assert abs(a - b) <= 1e-9 * a, costs
+    for a, b, c in zip(costs[0], costs[1], costs[2]):
+        assert abs(a - b) <= 1e-9 * a and abs(a - c) <= 1e-9 * a, costs
 
 
 def test_ineligible_patterns_keep_the_pair_path():
