@@ -2,13 +2,18 @@
 """Benchmark of the bundle-adjustment Gauss-Newton iteration on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--visibility MODE]
+                    [--scaling weak|strong]
 
 A step is one full Gauss-Newton iteration of the reference's loop (per-camera records,
 Jacobian blocks and predictions, Schur assembly, reduced camera solve, back-substitution with
 the point update, camera update, cost) on synthetic data that is resident in HBM before the
-timed region starts.  With N > 1 (one process per GPU under torch.distributed.run) every rank
-holds the workload's point count (weak scaling: N x points, same cameras) and the camera
-system is all-reduced over RCCL each iteration.  Rank 0 prints one JSON line.
+timed region starts.  With N > 1 there is one process per GPU: either the ranks come from
+`python -m torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or, when
+WORLD_SIZE is unset, this script starts the N rank processes itself before it touches a GPU.
+`--scaling weak` (default): every rank holds the workload's point count (N x points, same
+cameras).  `--scaling strong`: ONE problem (default workload venice1800, 1 M points) is
+sharded by point id over the N ranks.  The camera system is all-reduced over RCCL each
+iteration.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -25,16 +30,19 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
 FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector = matrix peak (datasheet)
 
 
-def algorithmic_bytes(N, n, m, s_blocks):
+def algorithmic_bytes(N, n, m, s_blocks, with_B=False):
     """Bytes per Gauss-Newton iteration a kernel group must move at minimum (fp64 values, int32
-    indices, A and B materialised as the reference's interface dictates).  `s_blocks` = number of
-    7 x 7 blocks of S that hold a non-zero (camera pairs with a shared point, both triangles):
-    m * m when every pair of cameras shares a point, far fewer for banded visibility - only those
-    blocks are written."""
+    indices).  `s_blocks` = number of 7 x 7 blocks of S that hold a non-zero (camera pairs with a
+    shared point, both triangles): m * m when every pair of cameras shares a point, far fewer for
+    banded visibility - only those blocks are written.  The loop reads dF/dX = -dF/dC out of the
+    rows of A and never materialises B: 136 / 152 / 120 bytes per observation for the three stages.
+    `with_B` prices B (48 bytes per observation) as a materialised array as well, which is what the
+    reference's interface hands between its stages: 184 / 200 / 168."""
+    b = 48 if with_B else 0
     return {
-        "jacobian": 184 * N + 24 * n + 128 * m,
-        "assembly": 200 * N + 96 * n + 392 * s_blocks + 560 * m,
-        "back_substitution": 168 * N + 120 * n + 56 * m,
+        "jacobian": (136 + b) * N + 24 * n + 128 * m,
+        "assembly": (152 + b) * N + 96 * n + 392 * s_blocks + 560 * m,
+        "back_substitution": (120 + b) * N + 120 * n + 56 * m,
     }
 
 
@@ -50,13 +58,19 @@ GROUPS = {
 
 def measured_traffic(workload, visibility):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE with the
-    gfx950 read-side correction), or {} when none was taken for this workload."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get(f"{workload}/{visibility}", {})
-    except (OSError, ValueError):
-        return {}
+    gfx950 read-side correction), or {} when none was taken for this workload.  The newest file that
+    holds the workload wins (kernels change between rounds of measurements)."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                doc = json.load(f).get(f"{workload}/{visibility}")
+        except (OSError, ValueError):
+            continue
+        if doc:
+            return doc
+    return {}
 
 
 def cpu_baseline(workload, visibility, seed, sample_points=100000, iters=4):
@@ -188,20 +202,142 @@ def pnp_line(n, reps):
                                             np.max(np.abs(Tg - To)) / np.max(np.abs(To))))}))
 
 
+def free_port():
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n_ranks):
+    """Start `n_ranks` copies of this command line as rank processes (one per GPU) and wait for them.
+    Runs before anything in this process has touched a GPU: the children are fresh interpreters with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, as torch.distributed.run would set
+    them; rank 0's standard output (the JSON line) is this process's.  Returns the exit code: 0 when
+    every rank ended with 0, else the first non-zero code (the other ranks are ended then)."""
+    import subprocess
+
+    backend = os.environ.get("SFM_BA_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        import torch
+
+        have = torch.cuda.device_count()  # counts devices without initialising the runtime
+        if have < n_ranks:
+            print(f"bench.py: --gpus {n_ranks} needs {n_ranks} visible GPUs, found {have} "
+                  f"(SFM_BA_BENCH_BACKEND=gloo rehearses the multi-rank path on one GPU)", file=sys.stderr)
+            return 2
+    env = dict(os.environ, WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n_ranks):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for pr in list(pending):
+            code = pr.poll()
+            if code is None:
+                continue
+            pending.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in pending:   # a rank died: its peers would wait in a collective for ever
+                    other.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def stage_times(prob, steps, warmup, world, barrier):
+    """(wall seconds for `steps` iterations with the stage kernels timed, per-kernel (ms total, launches))."""
+    from sfm_amd import _lib
+
+    for _ in range(warmup):
+        prob.iterate_async()
+    barrier()
+    prob.check_flags()
+    _lib.profile_read()
+    # HIP events on the launch stream around the kernels of the three HBM stages and around the
+    # reduced solve (what the roofline object is computed from).  A single rank enqueues nothing
+    # between the library's launches, so consecutive timed launches share an event.
+    timed = sorted({k for names in GROUPS.values() for k in names} | {"solve_reduced"})
+    _lib.profile_enable(True, chained=(world == 1), kernels=timed)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        prob.iterate_async()
+    barrier()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    return dt, _lib.profile_read()
+
+
+def stage_groups(prof, steps, N, n, m, s_blocks, pmc):
+    """Per-stage record: time, the bytes the loop must move (headline GB/s) and the same with B priced
+    as a materialised array, counter traffic where a PMC pass of these kernels is on file."""
+    alg, alg_b = algorithmic_bytes(N, n, m, s_blocks), algorithmic_bytes(N, n, m, s_blocks, with_B=True)
+    groups = {}
+    for g, names in GROUPS.items():
+        present = [nm for nm in names if nm in prof]
+        ms = sum(prof[nm][0] for nm in present) / steps
+        traffic = None
+        if present and all(nm in pmc for nm in present):
+            traffic = sum(pmc[nm]["bytes"] * prof[nm][1] / steps for nm in present)
+        groups[g] = {"ms": ms, "kernels": present, "bytes": alg[g],
+                     "GBps": alg[g] / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                     "bytes_with_B": alg_b[g],
+                     "GBps_with_B": alg_b[g] / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                     "traffic": traffic,
+                     "traffic_GBps": traffic / (ms * 1e-3) / 1e9 if traffic and ms > 0 else None}
+    return groups
+
+
+def solve_record(prof, steps, n7, hb):
+    solve_ms = prof.get("solve_reduced", (0.0, 1))[0] / steps
+    if hb <= 64:
+        # band Cholesky + two band substitutions
+        flops, path = n7 * (hb + 1.0) ** 2 + 4.0 * n7 * (hb + 1.0), "block cyclic reduction (band)"
+    else:
+        flops, path = n7 ** 3 / 3.0 + 2.0 * n7 * n7, "blocked Cholesky (dense)"
+    return {
+        "bound": "latency" if hb <= 64 else "mfma",
+        "path": path,
+        "half_bandwidth": hb,
+        "flops": flops,
+        "ms": solve_ms,
+        "achieved": flops / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else None,
+        "peak": FP64_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c4_500x300k")
+    ap.add_argument("--workload", default=None,
+                    help="default: c4_500x300k (weak scaling), venice1800 (strong scaling)")
     ap.add_argument("--visibility", default="banded", choices=["banded", "uniform"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the workload's point count per GPU; strong: one problem sharded over the GPUs")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-uniform-record", action="store_true",
+                    help="skip the short extra run of the same workload with uniform visibility")
     ap.add_argument("--triangulate", type=int, default=0, metavar="N",
                     help="benchmark the two-view triangulation kernel on N correspondences instead")
     ap.add_argument("--pnp", type=int, default=0, metavar="N",
                     help="benchmark RANSAC linear PnP on N correspondences instead")
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "venice1800" if args.scaling == "strong" else "c4_500x300k"
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     if args.pnp > 0:
         pnp_line(args.pnp, max(args.steps, 1))
         return
@@ -209,8 +345,28 @@ def main():
         triangulation_line(args.triangulate, max(args.steps, 1))
         return
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
     import torch
     import torch.distributed as dist
+
+    if os.environ.get("SFM_BA_BENCH_SELFTEST"):
+        # launcher check without a GPU: the ranks meet over gloo, add up their ranks, rank 0 reports
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t)
+        if os.environ.get("SFM_BA_BENCH_SELFTEST") == f"fail{rank}":
+            os._exit(7)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"selftest": True, "n_gpus": world, "scaling": args.scaling, "workload": args.workload,
+                              "rank_sum": float(t.item())}))
+        dist.destroy_process_group()
+        return
 
     import sfm_amd  # noqa: F401
     from sfm_amd import _lib, synthetic
@@ -222,16 +378,13 @@ def main():
         import faulthandler
 
         faulthandler.dump_traceback_later(int(os.environ["SFM_BA_BENCH_WATCHDOG"]), exit=True)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # Rehearsal on a box with fewer GPUs than ranks: SFM_BA_BENCH_BACKEND=gloo puts every rank on
     # GPU 0 and moves the buffers with gloo (RCCL refuses two ranks on one device).  The numbers of
     # such a run mean nothing; it exists to exercise the multi-rank code path.
     backend = os.environ.get("SFM_BA_BENCH_BACKEND", "nccl")
     if backend == "nccl":
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPUs are visible")
         torch.cuda.set_device(local_rank)
     else:
         torch.cuda.set_device(0)
@@ -243,8 +396,8 @@ def main():
             dist.init_process_group(backend)
         group = dist.group.WORLD
 
-    m, n_per_gpu, k = synthetic.WORKLOADS[args.workload]
-    n_total = n_per_gpu * world
+    m, n_workload, k = synthetic.WORKLOADS[args.workload]
+    n_total = n_workload * world if args.scaling == "weak" else n_workload
     full = synthetic.make_workload(args.workload, visibility=args.visibility, seed=args.seed, points=n_total)
     N_total = full.n_obs
     if world > 1:
@@ -264,25 +417,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        prob.iterate_async()
-    barrier()
-    prob.check_flags()
-    _lib.profile_read()
-
-    # timed region: K iterations; HIP events on the launch stream around the kernels of the three HBM
-    # stages and around the reduced solve (what the roofline object is computed from).  A single rank
-    # enqueues nothing between the library's launches, so consecutive timed launches share an event.
-    timed = sorted({k for names in GROUPS.values() for k in names} | {"solve_reduced"})
-    _lib.profile_enable(True, chained=(world == 1), kernels=timed)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        prob.iterate_async()
-    barrier()
-    dt = time.perf_counter() - t0
-    _lib.profile_enable(False)
-    prof = _lib.profile_read()
+    # timed region: K iterations after W warm-up iterations
+    dt, prof = stage_times(prob, args.steps, args.warmup, world, barrier)
     final_cost = float(prob.cost_buf.item())
     prob.check_flags()
     if world > 1:
@@ -310,19 +446,8 @@ def main():
     if rank == 0:
         per_kernel = {name: {"ms_avg": ms / cnt, "launches_per_step": cnt / args.steps} for name, (ms, cnt) in prof.items()}
         s_blocks = 2 * prob.plan.n_blocks - m  # plan counts pairs j <= k
-        alg = algorithmic_bytes(N_loc, n_loc, m, s_blocks)
         pmc = measured_traffic(args.workload, args.visibility) if world == 1 else {}
-        groups = {}
-        for g, names in GROUPS.items():
-            present = [nm for nm in names if nm in prof]
-            ms = sum(prof[nm][0] for nm in present) / args.steps
-            traffic = None
-            if present and all(nm in pmc for nm in present):
-                traffic = sum(pmc[nm]["bytes"] * prof[nm][1] / args.steps for nm in present)
-            groups[g] = {"ms": ms, "kernels": present, "bytes": alg[g],
-                         "GBps": alg[g] / (ms * 1e-3) / 1e9 if ms > 0 else None,
-                         "traffic": traffic,
-                         "traffic_GBps": traffic / (ms * 1e-3) / 1e9 if traffic and ms > 0 else None}
+        groups = stage_groups(prof, args.steps, N_loc, n_loc, m, s_blocks, pmc)
         # the dominant HBM-bound stage; its algorithmic bytes are defined per stage, so a stage that
         # takes several kernels is priced as one unit (the slowest kernel inside it is named)
         dominant = max(groups, key=lambda g: groups[g]["ms"])
@@ -336,29 +461,15 @@ def main():
             "unit": "GB/s",
             "frac": groups[dominant]["GBps"] / HBM_PEAK_GBS,
             "traffic": groups[dominant]["traffic"],
+            "achieved_with_B": groups[dominant]["GBps_with_B"],
+            "frac_with_B": groups[dominant]["GBps_with_B"] / HBM_PEAK_GBS,
             "groups": groups,
-            "note": "algorithmic bytes count A and B as materialised arrays (184 / 200 / 168 bytes per observation "
-                    "for the three stages); the loop itself no longer writes B (dF/dX = -dF/dC is read from A), "
-                    "which would make them 136 / 152 / 120",
+            "note": "achieved / frac and every group's GBps price the bytes the loop has to move: 136 / 152 / 120 "
+                    "bytes per observation for Jacobian / assembly / back-substitution (dF/dX = -dF/dC is read from "
+                    "the rows of A, B is never written); the *_with_B fields add B as a materialised array "
+                    "(184 / 200 / 168), the form in which the reference hands the blocks between its stages",
         }
         n7 = 7 * m
-        solve_ms = prof.get("solve_reduced", (0.0, 1))[0] / args.steps
-        hb = prob.half_bandwidth
-        if hb <= 64:
-            # band Cholesky + two band substitutions
-            flops, path = n7 * (hb + 1.0) ** 2 + 4.0 * n7 * (hb + 1.0), "block cyclic reduction (band)"
-        else:
-            flops, path = n7 ** 3 / 3.0 + 2.0 * n7 * n7, "blocked Cholesky (dense)"
-        solve = {
-            "bound": "latency" if hb <= 64 else "mfma",
-            "path": path,
-            "half_bandwidth": hb,
-            "flops": flops,
-            "ms": solve_ms,
-            "achieved": flops / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else None,
-            "peak": FP64_PEAK_TFLOPS,
-            "unit": "TFLOP/s",
-        }
         out = {
             "metric": "BA Gauss-Newton observations/sec (synthetic %d cams x %d pts)" % (m, n_total),
             "value": N_total * args.steps / dt,
@@ -370,23 +481,45 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "ms_per_step_without_events": dt_plain / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: {m} cameras x {n_total} points x {N_total} observations, "
-                            f"{args.visibility} visibility, seed {args.seed}, {n_per_gpu} points per GPU",
+                            f"{args.visibility} visibility, seed {args.seed}, "
+                            + (f"{n_workload} points per GPU" if args.scaling == "weak"
+                               else f"one problem sharded by point id over {world} GPU(s)"),
                 "cameras": m, "points": n_total, "observations": N_total, "visibility": args.visibility,
                 "nonzero_S_blocks": s_blocks,
+                "assembly": "fused point-major" if prob.plan.fused else "camera-pair",
                 "parallelism": "1 gpu" if world == 1 else f"point-id sharding x{world}, all-reduce of "
                                f"{packed_system_elements(m, prob.half_bandwidth) * 8 / 1e6:.1f} MB per iteration",
             },
             "final_cost": final_cost,
             "roofline": roofline,
-            "solve": solve,
+            "solve": solve_record(prof, args.steps, n7, prob.half_bandwidth),
             "kernels": per_kernel,
         }
+        if world == 1 and args.visibility == "banded" and not args.no_uniform_record:
+            # the same workload with every point seen by cameras drawn uniformly: dense S, camera-pair assembly
+            del prob
+            torch.cuda.empty_cache()
+            u = synthetic.make_workload(args.workload, visibility="uniform", seed=args.seed, points=n_total)
+            up = DeviceProblem(u.K, u.R, u.T, u.X, u.cam_idx, u.pt_idx, u.x_true, n_cams=m, check=True,
+                               plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"))
+            usteps = max(2, min(args.steps, 5))
+            udt, uprof = stage_times(up, usteps, 2, 1, barrier)
+            up.check_flags()
+            ub = 2 * up.plan.n_blocks - m
+            out["uniform_visibility"] = {
+                "workload": f"{args.workload}: {m} cameras x {u.n} points x {u.n_obs} observations, uniform visibility",
+                "steps": usteps, "ms_per_step": udt / usteps * 1e3, "value": u.n_obs * usteps / udt, "unit": "obs/s",
+                "nonzero_S_blocks": ub,
+                "groups": stage_groups(uprof, usteps, up.N, up.n, m, ub, measured_traffic(args.workload, "uniform")),
+                "solve": solve_record(uprof, usteps, n7, up.half_bandwidth),
+            }
+            del up, u
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.visibility, args.seed)
         print(json.dumps(out))

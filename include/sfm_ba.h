@@ -127,7 +127,9 @@ int64_t sfm_ba_plan_workspace_bytes(const sfm_ba_plan* plan);
  *   (k_stride = 9 or 0; the Jacobians read fx=K[0], fy=K[4], ox=K[2], oy=K[5] only, as
  *   src/jacobian.py:22-25 does); d_cam_blk [m, SFM_BA_CAM_BLK] out:
  *     [0..8] mixed rows, [9..11] C, [12..47] dR/dQ (9x4 row-major), [48..51] Q, [52..55] fx,fy,ox,oy
- *   d_flags [m] int32 out (OR-ed): SFM_BA_FLAG_DET_NOT_ONE where the reference would assert.
+ *   d_flags [m] int32 in/out: SFM_BA_FLAG_DET_NOT_ONE is OR-ed in where the reference would assert.
+ *   Flag words are sticky: the kernels only ever set bits, so a caller that enqueues several
+ *   iterations and checks once sees what any of them raised; the caller zeroes the array.
  * ---------------------------------------------------------------------------------------- */
 int sfm_ba_camera_prepare(const double* d_R, const double* d_C, const double* d_K, int k_stride,
                           int32_t m, double* d_cam_blk, int32_t* d_flags, void* stream);
@@ -213,6 +215,24 @@ int sfm_ba_calc_W_Y(const sfm_ba_plan* plan, const double* d_A, const double* d_
  * add mu to the 7m diagonal entries of d_S (the one place mu enters U, src/sparse_ba.py:194-197). */
 int sfm_ba_add_diagonal(double* d_S, int32_t n7, double mu, void* stream);
 
+/* One read for everything the reference's loop looks at after an iteration
+ * (src/bundle_adjustment.py:75-105: the cost it prints and compares, and the exceptions numpy or its
+ * own asserts would have raised): d_status [3] doubles = { d_cost[0], d_info[0], OR over the m
+ * cameras of d_flags_a[j] | d_flags_b[j] }.  Any input may be NULL (reads as 0). */
+int sfm_ba_iteration_status(const double* d_cost, const int32_t* d_info, const int32_t* d_flags_a,
+                            const int32_t* d_flags_b, int32_t m, double* d_status, void* stream);
+
+/* What the ranks of a sharded run exchange when S is dense: the lower triangle of d_S (row i:
+ * columns 0 .. i, at offset i (i + 1) / 2) followed by the right-hand side (row n7 of the system
+ * buffer) - sfm_ba_lower_elements(n7) = n7 (n7 + 1) / 2 + n7 doubles, half of the buffer.  The sums
+ * over points of calc_S / calc_e (src/sparse_ba.py:237-271) are formed per rank; S is symmetric and
+ * the solvers read its lower triangle only.  sfm_ba_lower_pack fills d_tri from d_S, the ranks
+ * all-reduce d_tri, sfm_ba_lower_unpack writes it back into the lower triangle and row n7 of d_S
+ * and adds mu to the diagonal (the one place mu enters U, src/sparse_ba.py:194-197). */
+int64_t sfm_ba_lower_elements(int32_t n7);
+int sfm_ba_lower_pack(const double* d_S, int32_t n7, double* d_tri, void* stream);
+int sfm_ba_lower_unpack(const double* d_tri, int32_t n7, double mu, double* d_S, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Reduced camera system.  Work of `calc_delta_a` (src/sparse_ba.py:274-276): solves
  * S delta_a = e.  The reference calls LAPACK dgesv (LU); S is symmetric positive definite
@@ -221,8 +241,10 @@ int sfm_ba_add_diagonal(double* d_S, int32_t n7, double mu, void* stream);
  *   d_S [(n7+1), n7] as written by sfm_ba_schur_assemble (row n7 = right-hand side); destroyed
  *   d_delta_a [n7] out
  *   d_chol_ws : sfm_ba_cholesky_workspace_bytes(n7) bytes
- *   d_info [1] int32: 0, or 1+index of the first non-positive pivot (SFM_BA_ENOTPD semantics;
- *          read it after synchronising the stream)
+ *   d_info [1] int32 in/out: zeroed by the caller; a factorisation that meets a non-positive pivot
+ *          writes 1+its index if the word still holds 0 (SFM_BA_ENOTPD semantics), so the word keeps
+ *          the first failure of all the solves enqueued since the caller cleared it; read it after
+ *          synchronising the stream
  * ---------------------------------------------------------------------------------------- */
 int64_t sfm_ba_cholesky_workspace_bytes(int32_t n7);
 int sfm_ba_solve_reduced(double* d_S, int32_t n7, double* d_delta_a, void* d_chol_ws,
@@ -277,8 +299,8 @@ int sfm_ba_back_substitute(const sfm_ba_plan* plan, const double* d_A, const dou
  * Q = quat(R) + q_step*delta_a[0:4], normalised; R = rot(Q); C' = C + c_step*delta_a[4:7];
  * T = -R C'; C = -R^T T; P = K [R|T] (d_K [m,9] or [1,9], k_stride 9 or 0; d_P may be NULL).
  * The reference skips frame 0 (first_cam = 1) and uses
- * q_step = 1, c_step = 0.1.  d_flags [m] receives SFM_BA_FLAG_ZERO_QUAT where the reference
- * would raise ValueError.
+ * q_step = 1, c_step = 0.1.  SFM_BA_FLAG_ZERO_QUAT is OR-ed into d_flags [m] where the reference
+ * would raise ValueError (sticky, see sfm_ba_camera_prepare).
  * ---------------------------------------------------------------------------------------- */
 int sfm_ba_update_cameras(double* d_R, double* d_T, double* d_C, double* d_P, const double* d_K,
                           int k_stride, const double* d_delta_a, int32_t m, int32_t first_cam,

@@ -42,6 +42,10 @@ SYMBOLS = {
     "sfm_ba_back_substitute_steps": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp]),
     "sfm_ba_calc_W_Y": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_ba_add_diagonal": (_int, [_vp, _i32, _f64, _vp]),
+    "sfm_ba_iteration_status": (_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "sfm_ba_lower_elements": (_i64, [_i32]),
+    "sfm_ba_lower_pack": (_int, [_vp, _i32, _vp, _vp]),
+    "sfm_ba_lower_unpack": (_int, [_vp, _i32, _f64, _vp, _vp]),
     "sfm_ba_cholesky_workspace_bytes": (_i64, [_i32]),
     "sfm_ba_solve_reduced": (_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "sfm_ba_solve_reduced_banded": (_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),

@@ -84,6 +84,24 @@ int sfm_ba_add_diagonal(double* d_S, int32_t n7, double mu, void* stream) {
   return launch_add_diagonal(d_S, n7, mu, static_cast<hipStream_t>(stream));
 }
 
+int sfm_ba_iteration_status(const double* d_cost, const int32_t* d_info, const int32_t* d_flags_a,
+                            const int32_t* d_flags_b, int32_t m, double* d_status, void* stream) {
+  if (!d_status || m < 0) return SFM_BA_EINVAL;
+  return launch_status(d_cost, d_info, d_flags_a, d_flags_b, m, d_status, static_cast<hipStream_t>(stream));
+}
+
+int64_t sfm_ba_lower_elements(int32_t n7) { return n7 > 0 ? (int64_t)n7 * (n7 + 1) / 2 + n7 : 0; }
+
+int sfm_ba_lower_pack(const double* d_S, int32_t n7, double* d_tri, void* stream) {
+  if (!d_S || !d_tri || n7 < 0) return SFM_BA_EINVAL;
+  return launch_lower_pack(d_S, n7, d_tri, static_cast<hipStream_t>(stream));
+}
+
+int sfm_ba_lower_unpack(const double* d_tri, int32_t n7, double mu, double* d_S, void* stream) {
+  if (!d_S || !d_tri || n7 < 0) return SFM_BA_EINVAL;
+  return launch_lower_unpack(d_tri, n7, mu, d_S, static_cast<hipStream_t>(stream));
+}
+
 int64_t sfm_ba_cholesky_workspace_bytes(int32_t n7) { return n7 > 0 ? cholesky_workspace_bytes(n7) : 0; }
 
 int sfm_ba_solve_reduced(double* d_S, int32_t n7, double* d_delta_a, void* d_chol_ws, int32_t* d_info,

@@ -1174,11 +1174,6 @@ int launch_solve_band_packed(double* packed, int n, double mu_diag, double* da, 
   double* ek = Bk + (int64_t)np * NB * NB;
   double* Pu = static_cast<double*>(ws);
   double* Pd = Pu + (int64_t)np * NB * NB;
-  hipError_t err = hipMemsetAsync(info, 0, sizeof(int32_t), st);
-  if (err != hipSuccess) {
-    set_hip_error(err, "hipMemsetAsync(info)");
-    return SFM_BA_EHIP;
-  }
   if (mu_diag != 0.0) hipLaunchKernelGGL(k_bcr_add_diagonal, dim3((n + 255) / 256), dim3(256), 0, st, Dk, n, mu_diag);
   int s = 1;
   for (; s < np; s *= 2) {
@@ -1213,11 +1208,6 @@ int launch_solve_reduced(double* S, int n, int half_bandwidth, double* da, void*
   double* invL = static_cast<double*>(ws);
   double* y = invL + (int64_t)np * NB * NB;
   int32_t* zflags = reinterpret_cast<int32_t*>(y + (int64_t)np * NB + 64);  // [np][np+1]
-  hipError_t err = hipMemsetAsync(info, 0, sizeof(int32_t), st);
-  if (err != hipSuccess) {
-    set_hip_error(err, "hipMemsetAsync(info)");
-    return SFM_BA_EHIP;
-  }
   if (half_bandwidth >= 0 && half_bandwidth <= NB) {
     if (np >= 4) {
       // packed form in the first part of the workspace, P_u / P_d behind it

@@ -175,6 +175,10 @@ int launch_back_substitute_steps(const sfm_ba_plan* p, const double* steps, cons
 int launch_calc_W_Y(const sfm_ba_plan* p, const double* A, const double* B, const double* w,
                     const double* Vinv, const int32_t* pt, double* W, double* Y, hipStream_t st);
 int launch_add_diagonal(double* S, int n7, double mu, hipStream_t st);
+int launch_status(const double* cost, const int32_t* info, const int32_t* fa, const int32_t* fb, int m, double* out,
+                  hipStream_t st);
+int launch_lower_pack(const double* S, int n7, double* tri, hipStream_t st);
+int launch_lower_unpack(const double* tri, int n7, double mu, double* S, hipStream_t st);
 int launch_back_substitute(const sfm_ba_plan* p, const double* A, const double* B, const double* w,
                            const double* Vinv, const double* eps_b, const double* da, double* db,
                            double* Xupd, double x_step, hipStream_t st);

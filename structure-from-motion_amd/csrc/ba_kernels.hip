@@ -125,7 +125,7 @@ __global__ void k_camera_prepare(const double* __restrict__ R, const double* __r
 #pragma unroll
   for (int i = 0; i < 3; ++i) cc[i] = C[3 * (int64_t)j + i];
   const int f = camera_record(rr, cc, K + (int64_t)k_stride * j, blk + (int64_t)SFM_BA_CAM_BLK * j);
-  if (flags) flags[j] = f;
+  if (flags && f) flags[j] |= f;  // sticky: the caller clears
 }
 
 // ------------------------------------------------------------------------------------------
@@ -318,6 +318,55 @@ __global__ __launch_bounds__(256) void k_jacobian_steps(
   for (int q = 0; q < 8; ++q) bp[64 * q] = out[q];
 }
 
+// One Jacobi rotation of a symmetric 3 x 3 matrix that annihilates a_pq; r is the third index.
+// vp, vq: the matching columns of the accumulated rotations.
+__device__ inline void jacobi_rot3(double& app, double& aqq, double& apq, double& arp, double& arq,
+                                   double (&vp)[3], double (&vq)[3]) {
+  if (apq == 0.0) return;
+  const double theta = (aqq - app) / (2.0 * apq);
+  const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+  const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
+  app -= tt * apq;
+  aqq += tt * apq;
+  apq = 0.0;
+  const double rp = c * arp - sn * arq, rq = sn * arp + c * arq;
+  arp = rp;
+  arq = rq;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double a = vp[i], b = vq[i];
+    vp[i] = c * a - sn * b;
+    vq[i] = sn * a + c * b;
+  }
+}
+
+// Moore-Penrose inverse of a symmetric 3 x 3 matrix (00 01 02 11 12 22 in, same out) as
+// numpy.linalg.pinv forms it (src/sparse_ba.py:201-212): eigenvalues whose magnitude is at most
+// 1e-15 times the largest are dropped.  Cyclic Jacobi sweeps; taken only for (nearly) rank-deficient
+// V_i, e.g. a point seen by a single camera with no damping.
+__device__ __noinline__ void pinv_sym3(double a00, double a01, double a02, double a11, double a12, double a22,
+                                       double (&out)[6]) {
+  double v0[3] = {1, 0, 0}, v1[3] = {0, 1, 0}, v2[3] = {0, 0, 1};
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    const double off = fabs(a01) + fabs(a02) + fabs(a12);
+    if (off == 0.0 || off <= 1e-300) break;
+    jacobi_rot3(a00, a11, a01, a02, a12, v0, v1);
+    jacobi_rot3(a00, a22, a02, a01, a12, v0, v2);
+    jacobi_rot3(a11, a22, a12, a01, a02, v1, v2);
+  }
+  const double big = fmax(fabs(a00), fmax(fabs(a11), fabs(a22)));
+  const double cut = 1e-15 * big;
+  const double i0 = fabs(a00) > cut ? 1.0 / a00 : 0.0;
+  const double i1 = fabs(a11) > cut ? 1.0 / a11 : 0.0;
+  const double i2 = fabs(a22) > cut ? 1.0 / a22 : 0.0;
+  out[0] = i0 * v0[0] * v0[0] + i1 * v1[0] * v1[0] + i2 * v2[0] * v2[0];
+  out[1] = i0 * v0[0] * v0[1] + i1 * v1[0] * v1[1] + i2 * v2[0] * v2[1];
+  out[2] = i0 * v0[0] * v0[2] + i1 * v1[0] * v1[2] + i2 * v2[0] * v2[2];
+  out[3] = i0 * v0[1] * v0[1] + i1 * v1[1] * v1[1] + i2 * v2[1] * v2[1];
+  out[4] = i0 * v0[1] * v0[2] + i1 * v1[1] * v1[2] + i2 * v2[1] * v2[2];
+  out[5] = i0 * v0[2] * v0[2] + i1 * v1[2] * v1[2] + i2 * v2[2] * v2[2];
+}
+
 // ------------------------------------------------------------------------------------------
 // per-point stage: V_i, V_i^-1, eps_b_i, then per observation g = w (eps - B V^-1 eps_b) and per
 // observation pair (a <= b) of the point the 2x2 coupling T_ab = (wB)_a V^-1 (wB)_b^T.
@@ -404,14 +453,25 @@ __global__ __launch_bounds__(256) void k_point(
     const double c22 = v00 * v11 - v01 * v01;
     const double det = v00 * c00 + v01 * c01 + v02 * c02;
     const double id = 1.0 / det;
-    const double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id, i11 = c11 * id, i12 = c12 * id, i22 = c22 * id;
+    double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id, i11 = c11 * id, i12 = c12 * id, i22 = c22 * id;
+    // (nearly) rank-deficient V_i - cond(V_i) beyond ~1e10, where the cofactor form has lost its
+    // digits, or det <= 0: the pseudo-inverse, as the reference's pinv gives it
+    const double tr = (v00 + v11 + v22) * (1.0 / 3.0);
+    if (!(det > 1e-10 * tr * tr * tr)) {
+      double pi[6];
+      pinv_sym3(v00, v01, v02, v11, v12, v22, pi);
+      i00 = pi[0]; i01 = pi[1]; i02 = pi[2]; i11 = pi[3]; i12 = pi[4]; i22 = pi[5];
+    }
     // V^-1 and V^-1 eps_b of the point go where the contributions of its first observation were:
-    // only this thread has read them
-    double* vz = sCon + 9 * (sPtr[t] - s0);
-    vz[0] = i00; vz[1] = i01; vz[2] = i02; vz[3] = i11; vz[4] = i12; vz[5] = i22;
-    vz[6] = i00 * a[6] + i01 * a[7] + i02 * a[8];
-    vz[7] = i01 * a[6] + i11 * a[7] + i12 * a[8];
-    vz[8] = i02 * a[6] + i12 * a[7] + i22 * a[8];
+    // only this thread has read them (a point without observations has no such place and nobody
+    // reads its record)
+    if (sPtr[t + 1] > sPtr[t]) {
+      double* vz = sCon + 9 * (sPtr[t] - s0);
+      vz[0] = i00; vz[1] = i01; vz[2] = i02; vz[3] = i11; vz[4] = i12; vz[5] = i22;
+      vz[6] = i00 * a[6] + i01 * a[7] + i02 * a[8];
+      vz[7] = i01 * a[6] + i11 * a[7] + i12 * a[8];
+      vz[8] = i02 * a[6] + i12 * a[7] + i22 * a[8];
+    }
     double* vo = Vinv + 9 * (int64_t)(p0 + t);
     vo[0] = i00; vo[1] = i01; vo[2] = i02;
     vo[3] = i01; vo[4] = i11; vo[5] = i12;
@@ -884,6 +944,24 @@ __global__ void k_add_diagonal(double* S, int n7, double mu) {
   if (i < n7) S[(int64_t)i * n7 + i] += mu;
 }
 
+// Lower triangle of S (row i: columns 0 .. i) followed by the right-hand side (row n7 of the
+// system buffer), and back.  What the ranks of a sharded run with a dense S exchange: the solvers
+// read the lower triangle only.  One workgroup per row; `mu` is added to the diagonal on the way back.
+__global__ __launch_bounds__(256) void k_lower_pack(const double* __restrict__ S, int n7, double* __restrict__ tri) {
+  const int i = blockIdx.x;
+  const int64_t at = (int64_t)i * (i + 1) / 2;
+  const int len = i < n7 ? i + 1 : n7;
+  for (int c = threadIdx.x; c < len; c += 256) tri[at + c] = S[(int64_t)i * n7 + c];
+}
+
+__global__ __launch_bounds__(256) void k_lower_unpack(const double* __restrict__ tri, int n7, double mu,
+                                                      double* __restrict__ S) {
+  const int i = blockIdx.x;
+  const int64_t at = (int64_t)i * (i + 1) / 2;
+  const int len = i < n7 ? i + 1 : n7;
+  for (int c = threadIdx.x; c < len; c += 256) S[(int64_t)i * n7 + c] = tri[at + c] + ((c == i) ? mu : 0.0);
+}
+
 // ------------------------------------------------------------------------------------------
 // back-substitution: delta_b_i = V_i^-1 (eps_b_i - sum_a B_a^T w_a A_a delta_a[cam_a])
 // ------------------------------------------------------------------------------------------
@@ -972,7 +1050,7 @@ __global__ void k_update_cameras(double* __restrict__ R, double* __restrict__ T,
 #pragma unroll
       for (int i = 0; i < 3; ++i) cc[i] = C[3 * (int64_t)j + i];
       const int pf = camera_record(r, cc, K + (int64_t)k_stride * j, blk + (int64_t)SFM_BA_CAM_BLK * j);
-      if (blk_flags) blk_flags[j] = pf;
+      if (blk_flags && pf) blk_flags[j] |= pf;
     }
     return;
   }
@@ -1014,10 +1092,10 @@ __global__ void k_update_cameras(double* __restrict__ R, double* __restrict__ T,
       }
     }
   }
-  if (flags) flags[j] = f;
+  if (flags && f) flags[j] |= f;  // sticky: the caller clears
   if (blk) {
     const int pf = camera_record(r, c, k, blk + (int64_t)SFM_BA_CAM_BLK * j);
-    if (blk_flags) blk_flags[j] = pf;
+    if (blk_flags && pf) blk_flags[j] |= pf;
   }
 }
 
@@ -1206,6 +1284,43 @@ int launch_add_diagonal(double* S, int n7, double mu, hipStream_t st) {
   if (n7 <= 0) return SFM_BA_OK;
   hipLaunchKernelGGL(k_add_diagonal, dim3((n7 + 255) / 256), dim3(256), 0, st, S, n7, mu);
   return check_launch("k_add_diagonal");
+}
+
+// [cost, info, OR of the camera flag words] as three doubles: what a caller needs to read after an
+// iteration, in one buffer
+__global__ __launch_bounds__(256) void k_status(const double* __restrict__ cost, const int32_t* __restrict__ info,
+                                                const int32_t* __restrict__ fa, const int32_t* __restrict__ fb, int m,
+                                                double* __restrict__ out) {
+  __shared__ int s_or[4];
+  int f = 0;
+  for (int j = threadIdx.x; j < m; j += 256) f |= (fa ? fa[j] : 0) | (fb ? fb[j] : 0);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) f |= __shfl_xor(f, o);
+  if ((threadIdx.x & 63) == 0) s_or[threadIdx.x >> 6] = f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = cost ? cost[0] : 0.0;
+    out[1] = info ? (double)info[0] : 0.0;
+    out[2] = (double)(s_or[0] | s_or[1] | s_or[2] | s_or[3]);
+  }
+}
+
+int launch_status(const double* cost, const int32_t* info, const int32_t* fa, const int32_t* fb, int m, double* out,
+                  hipStream_t st) {
+  hipLaunchKernelGGL(k_status, dim3(1), dim3(256), 0, st, cost, info, fa, fb, m, out);
+  return check_launch("k_status");
+}
+
+int launch_lower_pack(const double* S, int n7, double* tri, hipStream_t st) {
+  if (n7 <= 0) return SFM_BA_OK;
+  hipLaunchKernelGGL(k_lower_pack, dim3(n7 + 1), dim3(256), 0, st, S, n7, tri);
+  return check_launch("k_lower_pack");
+}
+
+int launch_lower_unpack(const double* tri, int n7, double mu, double* S, hipStream_t st) {
+  if (n7 <= 0) return SFM_BA_OK;
+  hipLaunchKernelGGL(k_lower_unpack, dim3(n7 + 1), dim3(256), 0, st, tri, n7, mu, S);
+  return check_launch("k_lower_unpack");
 }
 
 int launch_back_substitute(const sfm_ba_plan* p, const double* A, const double* B, const double* w,

@@ -244,7 +244,9 @@ class DeviceProblem:
             self.packed = torch.empty((int(self.lib.sfm_ba_band_packed_elements(n7)),), dtype=F64, device=d)
             self.compact = torch.empty((int(self.lib.sfm_ba_band_compact_elements(n7, self.half_bandwidth)),),
                                        dtype=F64, device=d)
+        self.tri = None  # dense sharded exchange buffer, allocated by the first such exchange
         self.cost_buf = torch.zeros((1,), dtype=F64, device=d)
+        self.status_buf = torch.zeros((3,), dtype=F64, device=d)
         # step blocks: rows of A and residuals in the order the fused assembly walks them (plans with runs)
         n_el = int(self.lib.sfm_ba_plan_steps_elements(self.plan.handle)) if self.use_steps else 0
         self.steps = torch.empty((n_el,), dtype=F64, device=d) if n_el > 0 else None
@@ -312,19 +314,20 @@ class DeviceProblem:
                 p(self.eps_a) if by_products else None,
                 p(self.V_inv), p(self.eps_b), None, p(self.workspace), _stream()))
         if reduce_packed:
-            import torch.distributed as dist
-
             # blocks and right-hand-side entries this rank never writes stay zero from allocation
             # (only the entries a band of this width can hold travel: about half of the packed form)
             _lib.check(self.lib.sfm_ba_band_compact(p(self.S), n7, self.half_bandwidth, p(self.compact), _stream()))
             self._all_reduce(self.compact)
             _lib.check(self.lib.sfm_ba_band_expand(p(self.compact), n7, self.half_bandwidth, p(self.packed), _stream()))
         elif self.sharded:
-            import torch.distributed as dist
-
+            # dense S: the lower triangle and the right-hand side travel (the solvers read nothing
+            # else), half of the buffer; the damping enters on the way back
             self._s_holds_foreign = True
-            self._all_reduce(self.sys[: (n7 + 1) * n7])
-            _lib.check(self.lib.sfm_ba_add_diagonal(p(self.S), n7, float(mu), _stream()))
+            if self.tri is None:
+                self.tri = torch.empty((int(self.lib.sfm_ba_lower_elements(n7)),), dtype=F64, device=self.device)
+            _lib.check(self.lib.sfm_ba_lower_pack(p(self.S), n7, p(self.tri), _stream()))
+            self._all_reduce(self.tri)
+            _lib.check(self.lib.sfm_ba_lower_unpack(p(self.tri), n7, float(mu), p(self.S), _stream()))
             self.e.copy_(self.S[n7].view(self.m, 7))
 
     def solve(self):
@@ -403,12 +406,27 @@ class DeviceProblem:
         self.update_cameras(prepare_next=True)
         self.cost_async()
 
-    def check_flags(self):
-        """Raise what the reference would have raised during the iterations run so far."""
-        info = int(self.info.item())
+    def status(self):
+        """(cost of the last iteration, pivot info, OR of the camera flag words) with one read."""
+        p = _lib.ptr
+        _lib.check(self.lib.sfm_ba_iteration_status(p(self.cost_buf), p(self.info), p(self.flags), p(self.upd_flags),
+                                                    self.m, p(self.status_buf), _stream()))
+        c, info, f = self.status_buf.tolist()
+        return c, int(info), int(f)
+
+    def clear_flags(self):
+        self.info.zero_()
+        self.flags.zero_()
+        self.upd_flags.zero_()
+
+    def check_flags(self, status=None):
+        """Raise what the reference would have raised during the iterations run since the flags were
+        last cleared (the device words are sticky; an exception clears them)."""
+        _, info, f = self.status() if status is None else status
+        if info != 0 or f != 0:
+            self.clear_flags()
         if info != 0:
             raise np.linalg.LinAlgError("Singular matrix")
-        f = int(torch.bitwise_or(self.flags, self.upd_flags).max().item()) if self.m else 0
         if f & _lib.FLAG_DET_NOT_ONE:
             raise AssertionError("Input matrix must have determinant 1 (be a rotation matrix)")
         if f & _lib.FLAG_ZERO_QUAT:
@@ -424,8 +442,9 @@ class DeviceProblem:
         n_iter = 0
         while (avg_error > threshold or n_iter < min_iter) and n_iter < max_iter:
             self.iterate_async()
-            avg_error = float(self.cost_buf.item())
-            self.check_flags()
+            st = self.status()   # the iteration's one host synchronisation
+            avg_error = st[0]
+            self.check_flags(st)
             costs.append(avg_error)
             if callback is not None:
                 callback(n_iter, avg_error)

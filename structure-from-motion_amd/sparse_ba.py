@@ -55,8 +55,13 @@ class SBA(object):
         return out["delta_a"], out["delta_b"]
 
     def compute_all(self, x_true, x_pred, A, B, weights=None, mu=0.0,
-                    want=("U", "V_inv", "W", "Y", "S", "epsilon_a", "epsilon_b", "e")):
-        """``compute`` that also returns the intermediates named in ``want``."""
+                    want=("U", "V_inv", "W", "Y", "S", "epsilon_a", "epsilon_b", "e"), solve=True):
+        """``compute`` that also returns the intermediates named in ``want``.  ``solve=False`` stops
+        after the assembly (no ``delta_a`` / ``delta_b``): with ``mu=0`` the reduced system of a free
+        network is singular, the reference's LU then returns numbers without meaning and the
+        Cholesky factorisation here raises ``LinAlgError``, but the assembled blocks are defined -
+        V_inv is the pseudo-inverse for a rank-deficient V_i, as ``numpy.linalg.pinv`` gives it
+        (``/root/reference/src/sparse_ba.py:201-212``)."""
         x_true = np.asarray(x_true, dtype=np.float64)
         x_pred = np.asarray(x_pred, dtype=np.float64)
         A = np.asarray(A, dtype=np.float64)
@@ -94,6 +99,8 @@ class SBA(object):
                                            _stream()))
             out["W"] = W.cpu().numpy().reshape(N, 7, 3)
             out["Y"] = Y.cpu().numpy().reshape(N, 7, 3)
+        if not solve:
+            return self._collect(out, want, m, n, U, V_inv, eps_a, eps_b, e)
         delta_a = torch.empty((m, 7), dtype=F64, device=d)
         delta_b = torch.empty((n, 3), dtype=F64, device=d)
         chol_ws = torch.empty((int(lib.sfm_ba_cholesky_workspace_bytes(n7)) // 8 + 8,), dtype=F64, device=d)
@@ -105,6 +112,10 @@ class SBA(object):
             raise np.linalg.LinAlgError("Singular matrix")
         out["delta_a"] = delta_a.cpu().numpy()
         out["delta_b"] = delta_b.cpu().numpy()
+        return self._collect(out, want, m, n, U, V_inv, eps_a, eps_b, e)
+
+    @staticmethod
+    def _collect(out, want, m, n, U, V_inv, eps_a, eps_b, e):
         if "U" in want:
             out["U"] = U.cpu().numpy().reshape(m, 7, 7)
         if "V_inv" in want:

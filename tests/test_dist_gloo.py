@@ -75,14 +75,17 @@ def _worker(rank, world, port, q):
 
         S, e, ssq, (A, B, V_inv, W, eps_b) = _partial_system(local, m, mu)
         n7 = 7 * m
+        from sfm_amd.dist import pack_lower, unpack_lower
+
+        nt = n7 * (n7 + 1) // 2 + n7
+        assert packed_system_elements(m) == nt + m  # lower triangle of S, e, per-camera cost sums
         buf = torch.zeros(packed_system_elements(m), dtype=torch.float64)
-        buf[: n7 * n7] = torch.from_numpy(S.reshape(-1))
-        buf[n7 * n7: (n7 + 1) * n7] = torch.from_numpy(e.reshape(-1))
-        buf[(n7 + 1) * n7:] = torch.from_numpy(ssq)
+        buf[:nt] = torch.from_numpy(pack_lower(S, e))
+        buf[nt:] = torch.from_numpy(ssq)
         dist.all_reduce(buf)
-        Sg = buf[: n7 * n7].numpy().reshape(n7, n7) + mu * np.identity(n7)   # damping enters once
-        eg = buf[n7 * n7: (n7 + 1) * n7].numpy()
-        cost = float(np.sqrt(buf[(n7 + 1) * n7:].numpy()).sum() / m)
+        Sg, eg = unpack_lower(buf[:nt].numpy(), n7)
+        Sg = Sg + mu * np.identity(n7)   # damping enters once
+        cost = float(np.sqrt(buf[nt:].numpy()).sum() / m)
         delta_a = np.linalg.solve(Sg, eg).reshape(m, 7)
         vi, pi = local.cam_idx.astype(np.int64), local.pt_idx.astype(np.int64)
         from oracle import ba_oracle as orc
@@ -148,3 +151,41 @@ def test_shard_bounds_balance():
         sizes = [local_problem(p, r, world)[0].n_obs for r in range(world)]
         assert sum(sizes) == p.n_obs
         assert max(sizes) - min(sizes) <= 8  # within one point's observations of each other
+
+
+def test_shard_bounds_never_empty():
+    """Skewed counts (one point holds almost every observation) and as many ranks as points: every
+    rank still owns a point; fewer points than ranks is an error raised before any collective."""
+    sys.path.insert(0, ROOT)
+    import sfm_amd  # noqa: F401
+    from sfm_amd.dist import shard_bounds
+
+    pt = np.concatenate([np.zeros(1000, dtype=np.int32), np.arange(1, 6, dtype=np.int32)])
+    for world in (2, 3, 6):
+        b = shard_bounds(pt, 6, world)
+        assert b[0] == 0 and b[-1] == 6 and np.all(np.diff(b) >= 1), b
+    pt = np.concatenate([np.arange(5, dtype=np.int32), np.full(1000, 5, dtype=np.int32)])
+    for world in (2, 4, 6):
+        b = shard_bounds(pt, 6, world)
+        assert b[0] == 0 and b[-1] == 6 and np.all(np.diff(b) >= 1), b
+    with pytest.raises(ValueError):
+        shard_bounds(pt, 6, 7)
+
+
+def test_lower_triangle_layout():
+    sys.path.insert(0, ROOT)
+    import sfm_amd  # noqa: F401
+    from sfm_amd.dist import pack_lower, packed_system_elements, unpack_lower
+
+    rng = np.random.default_rng(0)
+    n7 = 21
+    M = rng.normal(size=(n7, n7))
+    S, e = M + M.T, rng.normal(size=n7)
+    buf = pack_lower(S, e)
+    assert buf.size == packed_system_elements(3) - 3
+    for i in (0, 5, 20):
+        assert np.array_equal(buf[i * (i + 1) // 2: i * (i + 1) // 2 + i + 1], S[i, : i + 1])
+    S2, e2 = unpack_lower(buf, n7)
+    assert np.array_equal(S2, S) and np.array_equal(e2, e)
+    # 49 MB instead of 98 MB at 500 cameras
+    assert abs(packed_system_elements(500) * 8 / 1e6 - 49.1) < 0.1

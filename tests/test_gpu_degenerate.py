@@ -1,0 +1,178 @@
+"""Degenerate point blocks: V_i of a point seen by one camera (rank 2) or by cameras on one viewing
+ray at mu = 0, where the reference's ``numpy.linalg.pinv`` (/root/reference/src/sparse_ba.py:201-212)
+returns the pseudo-inverse, and a point id without observations on a plan built with size hints
+(a rank of a sharded run, ``check=False`` callers)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem_with_single_views(seed=0):
+    from sfm_amd import synthetic
+
+    p = synthetic.make_problem(5, 60, 3, visibility="uniform", seed=seed)
+    # ten more points, each seen by exactly one camera
+    rng = np.random.default_rng(seed)
+    extra = 10
+    cam = np.concatenate([p.cam_idx, rng.integers(0, p.m, size=extra).astype(np.int32)])
+    pt = np.concatenate([p.pt_idx, (p.n + np.arange(extra)).astype(np.int32)])
+    return p, cam, pt, extra
+
+
+def test_pinv_of_rank_deficient_V_at_mu_zero():
+    from oracle import ba_oracle as orc
+    from sfm_amd.sparse_ba import SBA
+
+    p, cam, pt, extra = _problem_with_single_views()
+    rng = np.random.default_rng(1)
+    N = len(cam)
+    A = rng.normal(size=(N, 2, 7))
+    B = rng.normal(size=(N, 2, 3)) * np.array([300.0, 200.0, 5.0])
+    # two of the three-view points get parallel B rows in all views: rank 1
+    for i in (3, 17):
+        rows = np.nonzero(pt == i)[0]
+        B[rows] = B[rows[0], 0][None, None, :] * rng.normal(size=(len(rows), 2, 1))
+    x_true = rng.normal(size=(N, 2))
+    x_pred = x_true + rng.normal(size=(N, 2))
+    got = SBA(cam, pt).compute_all(x_true, x_pred, A, B, mu=0.0, want=("V_inv", "S", "e", "epsilon_b", "U"), solve=False)
+    assert "delta_a" not in got
+    n = p.n + extra
+    V = orc._segment_sum(pt.astype(np.int64), np.einsum("naq,nar->nqr", B, B), n)
+    ranks = np.linalg.matrix_rank(V)
+    assert (ranks[p.n:] == 2).all() and ranks[3] == 1 and ranks[17] == 1 and (np.delete(ranks[: p.n], [3, 17]) == 3).all()
+    ref = np.linalg.pinv(V)
+    assert np.isfinite(got["V_inv"]).all()
+    for i in range(n):
+        assert np.max(np.abs(got["V_inv"][i] - ref[i])) <= 1e-9 * np.max(np.abs(ref[i])), (i, ranks[i])
+    # the blocks built from V_inv follow: S and e against the oracle's, which calls numpy's pinv
+    S_ref, e_ref = _oracle_S_e(cam, pt, x_true, x_pred, A, B, ref)
+    assert np.max(np.abs(got["S"] - S_ref)) <= 1e-9 * np.max(np.abs(S_ref))
+    assert np.max(np.abs(got["e"] - e_ref)) <= 1e-9 * np.max(np.abs(e_ref))
+
+
+def _oracle_S_e(cam, pt, x_true, x_pred, A, B, V_inv):
+    from oracle import ba_oracle as orc
+
+    vi, pi = cam.astype(np.int64), pt.astype(np.int64)
+    m = int(vi.max()) + 1
+    n = int(pi.max()) + 1
+    U = orc._segment_sum(vi, np.einsum("nap,nar->npr", A, A), m)
+    W = np.einsum("nap,naq->npq", A, B)
+    Y = np.einsum("npq,nqr->npr", W, V_inv[pi])
+    S = orc.calc_S(vi, pi, m, U, Y, W)
+    eps = x_true - x_pred
+    eps_a = orc._segment_sum(vi, np.einsum("nap,na->np", A, eps), m)
+    eps_b = orc._segment_sum(pi, np.einsum("naq,na->nq", B, eps), n)
+    e = eps_a - orc._segment_sum(vi, np.einsum("npq,nq->np", Y, eps_b[pi]), m)
+    return S, e
+
+
+def test_regular_points_keep_the_closed_form_at_mu_zero():
+    """Full-rank V_i at mu = 0: inverse and pseudo-inverse coincide."""
+    from oracle import ba_oracle as orc
+    from sfm_amd import synthetic
+    from sfm_amd.sparse_ba import SBA
+
+    p = synthetic.make_problem(6, 200, 4, visibility="uniform", seed=3)
+    rng = np.random.default_rng(2)
+    N = p.n_obs
+    A = rng.normal(size=(N, 2, 7))
+    B = rng.normal(size=(N, 2, 3))
+    x = rng.normal(size=(N, 2))
+    got = SBA(p.cam_idx, p.pt_idx).compute_all(x, x * 0.5, A, B, mu=0.0, want=("V_inv",), solve=False)
+    V = orc._segment_sum(p.pt_idx.astype(np.int64), np.einsum("naq,nar->nqr", B, B), p.n)
+    ref = np.linalg.pinv(V)
+    assert np.max(np.abs(got["V_inv"] - ref) / np.max(np.abs(ref), axis=(1, 2), keepdims=True)) < 1e-10
+
+
+@pytest.mark.parametrize("vis,k", [("banded", 4), ("uniform", 4)])
+@pytest.mark.parametrize("where", ["last_of_group", "middle", "first"])
+def test_unobserved_point_on_a_hinted_plan(vis, k, where):
+    """A point id that no observation names (allowed when the caller passes the point count): the
+    sums of every other point, S and e are those of the problem without it; its own V_i is mu I."""
+    import torch
+
+    from sfm_amd import synthetic
+    from sfm_amd.device import DeviceProblem
+
+    p = synthetic.make_problem(12, 3000, k, visibility=vis, seed=5)
+    counts = np.bincount(p.pt_idx, minlength=p.n)
+    csum = np.cumsum(counts)
+    if where == "last_of_group":
+        # point groups of the per-point kernel hold at most 256 observations: put the empty id where a group fills up
+        gap = int(np.searchsorted(csum, 256, side="left")) + 1
+    elif where == "middle":
+        gap = p.n // 2
+    else:
+        gap = 0
+    pt_gap = np.where(p.pt_idx >= gap, p.pt_idx + 1, p.pt_idx).astype(np.int32)
+    X_gap = np.insert(p.X, gap, [0.1, 0.2, 9.0], axis=0)
+    mu = 0.5
+    ref = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true)
+    hol = DeviceProblem(p.K, p.R, p.T, X_gap, p.cam_idx, pt_gap, p.x_true, n_cams=p.m, check=False)
+    assert hol.n == p.n + 1 and hol.plan.fused == 0
+    ref.plan.set_fused(0)
+    out = []
+    for prob in (ref, hol):
+        prob.camera_prepare()
+        prob.jacobian()
+        prob.sys.zero_()
+        prob.assemble(mu)
+        prob.solve()
+        prob.back_substitute()
+        torch.cuda.synchronize()
+        n7 = 7 * p.m
+        out.append((torch.tril(prob.S[:n7]).cpu().numpy(), prob.e.cpu().numpy(), prob.V_inv.cpu().numpy(),
+                    prob.eps_b.cpu().numpy(), prob.delta_a.cpu().numpy(), prob.delta_b.cpu().numpy()))
+    keep = np.arange(p.n + 1) != gap
+    (S0, e0, V0, b0, da0, db0), (S1, e1, V1, b1, da1, db1) = out
+    assert np.max(np.abs(S0 - S1)) <= 1e-13 * np.max(np.abs(S0))
+    assert np.max(np.abs(e0 - e1)) <= 1e-13 * np.max(np.abs(e0))
+    assert np.array_equal(V0, V1[keep]) and np.array_equal(b0, b1[keep])
+    assert np.allclose(V1[gap].reshape(3, 3), np.identity(3) / mu, rtol=1e-14, atol=0)
+    assert not b1[gap].any() and not db1[gap].any()
+    assert np.max(np.abs(da0 - da1)) <= 1e-9 * np.max(np.abs(da0))
+    assert np.max(np.abs(db0 - db1[keep])) <= 1e-9 * np.max(np.abs(db0))
+
+
+def test_flag_words_are_sticky():
+    """A failure of an earlier enqueued iteration is still seen by a later check (the reference would
+    have raised at that iteration): flag bits are only ever set by the kernels, the pivot word keeps
+    the first failure; a raised check clears them."""
+    import torch
+
+    from sfm_amd import _lib, synthetic
+    from sfm_amd.device import DeviceProblem
+
+    p = synthetic.make_problem(8, 500, 4, visibility="uniform", seed=9)
+    prob = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true)
+    good = prob.R.clone()
+    prob.R[3] *= 1.5   # det != 1: rotation_matrix_to_quaternion of the reference asserts
+    prob.camera_prepare()
+    prob.R.copy_(good)
+    prob.camera_prepare()
+    prob.iterate_async()
+    prob.iterate_async()
+    with pytest.raises(AssertionError):
+        prob.check_flags()
+    prob.check_flags()    # cleared by the raise; the state itself is fine
+    cost, info, f = prob.status()
+    assert info == 0 and f == 0 and cost == float(prob.cost_buf.item())
+
+    lib, ptr = _lib.load(), _lib.ptr
+    n = 70
+    rng = np.random.default_rng(0)
+    M = rng.normal(size=(n, n))
+    spd = M @ M.T + n * np.identity(n)
+    bad = spd.copy()
+    bad[40, 40] = -1.0
+    info = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    ws = torch.empty((int(lib.sfm_ba_cholesky_workspace_bytes(n)) // 8 + 8,), dtype=torch.float64, device="cuda")
+    da = torch.empty((n,), dtype=torch.float64, device="cuda")
+    for mat in (bad, spd):
+        buf = torch.from_numpy(np.vstack([mat, np.ones((1, n))])).cuda()
+        _lib.check(lib.sfm_ba_solve_reduced(ptr(buf), n, ptr(da), ptr(ws), ptr(info), None))
+    assert int(info.item()) == 41   # the first solve's pivot, not overwritten by the good one
+    x = np.linalg.solve(spd, np.ones(n))
+    assert np.max(np.abs(da.cpu().numpy() - x)) < 1e-10 * np.max(np.abs(x))

@@ -1,6 +1,8 @@
 """The sharded GPU path: two processes share the one GPU of the test box, each owns half of the
-points, and the camera system is all-reduced between them (gloo moves the CUDA tensors; on a
-multi-GPU node the same code runs over RCCL).  Results must match the single-process GPU run."""
+points, and the camera system is summed between them.  The ranks meet over gloo, which reduces a
+host copy of the exchange buffer (``DeviceProblem._all_reduce``); on a multi-GPU node the same
+code hands the device buffer to RCCL - that branch needs one GPU per rank and is not exercised
+here.  Results must match the single-process GPU run."""
 import os
 import sys
 
@@ -12,9 +14,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-# (cameras, points, views): 84 unknowns = 2 blocks of 64; 420 unknowns = 7 blocks (three rounds of the
-# cyclic reduction).  Both are banded, so the ranks exchange the packed block-tridiagonal system.
-PROBLEMS = {"small": (12, 3000, 4), "chain7": (60, 6000, 5)}
+# (cameras, points, views, visibility): 84 unknowns = 2 blocks of 64; 420 unknowns = 7 blocks (three
+# rounds of the cyclic reduction).  The banded ones exchange the packed block-tridiagonal system;
+# "dense" (every pair of cameras shares points, half bandwidth 97 > 64) exchanges the lower triangle
+# of S and solves with the general Cholesky - blocks this rank's points never touch arrive from the peer.
+PROBLEMS = {"small": (12, 3000, 4, "banded"), "chain7": (60, 6000, 5, "banded"), "dense": (14, 3000, 4, "uniform")}
 
 
 def _worker(rank, world, port, q, which="small"):
@@ -32,12 +36,14 @@ def _worker(rank, world, port, q, which="small"):
         from sfm_amd.device import DeviceProblem
         from sfm_amd.dist import local_problem
 
-        m, n, k = PROBLEMS[which]
-        full = synthetic.make_problem(m, n, k=k, visibility="banded", seed=6)
+        m, n, k, vis = PROBLEMS[which]
+        full = synthetic.make_problem(m, n, k=k, visibility=vis, seed=6)
         loc, (p0, p1) = local_problem(full, rank, world)
         prob = DeviceProblem(loc.K, loc.R, loc.T, loc.X, loc.cam_idx, loc.pt_idx, loc.x_true, n_cams=full.m,
                              group=dist.group.WORLD, check=False)
-        assert prob.band_sharded
+        assert prob.band_sharded == (vis == "banded")
+        if vis != "banded":
+            assert prob.half_bandwidth > 64
         c0 = prob.cost()
         costs = prob.run(max_iter=3, threshold=0.0)
         R, T, C, P = prob.cameras()
@@ -46,7 +52,7 @@ def _worker(rank, world, port, q, which="small"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("which", ["small", "chain7"])
+@pytest.mark.parametrize("which", ["small", "chain7", "dense"])
 def test_two_ranks_match_single_process(which):
     import torch.multiprocessing as mp
 
@@ -67,8 +73,8 @@ def test_two_ranks_match_single_process(which):
         assert p.exitcode == 0
     results.sort(key=lambda r: r[0])
 
-    m, n, k = PROBLEMS[which]
-    full = synthetic.make_problem(m, n, k=k, visibility="banded", seed=6)
+    m, n, k, vis = PROBLEMS[which]
+    full = synthetic.make_problem(m, n, k=k, visibility=vis, seed=6)
     one = DeviceProblem(full.K, full.R, full.T, full.X, full.cam_idx, full.pt_idx, full.x_true)
     c0 = one.cost()
     costs = one.run(max_iter=3, threshold=0.0)
@@ -98,7 +104,7 @@ def test_forced_sharded_flow_single_rank():
     os.environ["MASTER_PORT"] = str(29900 + (os.getpid() % 90))
     dist.init_process_group("gloo", rank=0, world_size=1)
     try:
-        # uniform visibility: dense system, all-reduce of the whole buffer; banded: packed exchange
+        # uniform visibility: dense system, exchange of the lower triangle; banded: packed exchange
         for vis, packed in (("uniform", False), ("banded", True)):
             p = synthetic.make_problem(10 if vis == "uniform" else 40, 2000, k=4, visibility=vis, seed=2)
             a = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true)
