@@ -1188,7 +1188,7 @@ int launch_solve_band_packed(double* packed, int n, double mu_diag, double* da, 
     const int m = (np + s - 1) / s;
     hipLaunchKernelGGL(k_bcr_back, dim3(m / 2), dim3(256), 0, st, n, np, s, 1, Dk, Pu, Pd, ek, da);
   }
-  err = hipGetLastError();
+  const hipError_t err = hipGetLastError();
   if (err != hipSuccess) {
     set_hip_error(err, "cyclic reduction launches");
     return SFM_BA_EHIP;
@@ -1208,6 +1208,7 @@ int launch_solve_reduced(double* S, int n, int half_bandwidth, double* da, void*
   double* invL = static_cast<double*>(ws);
   double* y = invL + (int64_t)np * NB * NB;
   int32_t* zflags = reinterpret_cast<int32_t*>(y + (int64_t)np * NB + 64);  // [np][np+1]
+  hipError_t err = hipSuccess;
   if (half_bandwidth >= 0 && half_bandwidth <= NB) {
     if (np >= 4) {
       // packed form in the first part of the workspace, P_u / P_d behind it
