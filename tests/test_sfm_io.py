@@ -121,3 +121,47 @@ def test_bal_problem_runs_on_device(tmp_path):
     prob.iterate_async()
     prob.check_flags()
     assert float(prob.cost_buf.item()) < 1e-6
+
+
+@pytest.mark.parametrize("scene", ["box", "boot"])
+def test_readers_against_the_references_committed_outputs(scene, tmp_path):
+    """The readers on bytes of the files the reference has committed under data/stage1/<scene>/
+    (tests/golden/stage1_io.npz, built by tests/golden/make_stage1_io_fixture.py: the PLY header as
+    trimesh wrote it with the first 32 and the last vertex record, the first three extrinsics of
+    each camera file; expected values decoded there with struct / json)."""
+    import os
+
+    from sfm_amd import sfm_io
+
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stage1_io.npz"))
+    header = fx[f"{scene}_ply_header"].tobytes()
+    n = int(fx[f"{scene}_ply_n"])
+    assert f"element vertex {n}\n".encode() in header and header.startswith(b"ply\nformat binary_little_endian 1.0\n")
+    # a 33-vertex file with the reference's own header text (count patched) and its own records
+    small = header.replace(f"element vertex {n}\n".encode(), b"element vertex 33\n")
+    path = tmp_path / "points.ply"
+    path.write_bytes(small + fx[f"{scene}_ply_first32"].tobytes() + fx[f"{scene}_ply_last"].tobytes())
+    xyz, rgba = sfm_io.read_points_ply(str(path))
+    assert xyz.shape == (33, 3) and rgba.shape == (33, 4)
+    assert np.array_equal(xyz, fx[f"{scene}_ply_xyz"]) and np.array_equal(rgba, fx[f"{scene}_ply_rgba"])
+    assert np.all(xyz >= fx[f"{scene}_ply_min"]) and np.all(xyz <= fx[f"{scene}_ply_max"])
+    # what write_points_ply emits for these vertices is, past the comment line, the same file
+    out = tmp_path / "rewritten.ply"
+    sfm_io.write_points_ply(str(out), xyz, rgba)
+    mine = out.read_bytes()
+    strip = lambda b: b"\n".join(ln for ln in b.split(b"end_header\n")[0].split(b"\n") if not ln.startswith(b"comment"))  # noqa: E731
+    assert strip(mine) == strip(small)
+    assert mine.split(b"end_header\n", 1)[1] == path.read_bytes().split(b"end_header\n", 1)[1]
+
+    for kind in ("estimated", "gt"):
+        if f"{scene}_{kind}_json" not in fx:
+            continue
+        jp = tmp_path / f"{kind}.json"
+        jp.write_bytes(fx[f"{scene}_{kind}_json"].tobytes())
+        names, RT, K = sfm_io.read_camera_parameters(str(jp))
+        assert names == list(fx[f"{scene}_{kind}_names"])
+        assert RT.shape == (3, 3, 4) and np.array_equal(RT, fx[f"{scene}_{kind}_RT"])
+        if f"{scene}_{kind}_K" in fx:
+            assert np.array_equal(K, fx[f"{scene}_{kind}_K"])
+        else:
+            assert K is None
