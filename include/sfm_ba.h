@@ -34,14 +34,13 @@ extern "C" {
 #define SFM_BA_EMISSING_VIEW -5 /* viewpoint ids not contiguous 0..max    src/sparse_ba.py:91 */
 #define SFM_BA_ENOTPD -6        /* reduced camera system not positive definite (numpy raises LinAlgError
                                    for a singular S at src/sparse_ba.py:275) */
-#define SFM_BA_ETOOBIG -7       /* a point is observed by more cameras than SFM_BA_MAX_VIEWS */
+#define SFM_BA_ETOOBIG -7       /* the problem exceeds the plan's 32-bit offsets (2^32 / 112 observations,
+                                   about 134 M same-point observation pairs) or an entry point's stated maximum */
 
 /* doubles per prepared camera record (see sfm_ba_camera_prepare) */
 #define SFM_BA_CAM_BLK 56
 /* doubles per per-camera reduction record: 28 (upper triangle of U) + 7 (eps_a) + 7 (sum Y eps_b) + 1 (sum |eps|^2) */
 #define SFM_BA_CAM_RED 43
-/* largest number of observations of one point */
-#define SFM_BA_MAX_VIEWS 256
 
 /* flag bits written by sfm_ba_camera_prepare / sfm_ba_update_cameras into d_flags[camera] */
 #define SFM_BA_FLAG_DET_NOT_ONE 1   /* |det R - 1| > 1e-8 + 1e-5   src/utils.py:74-76 */

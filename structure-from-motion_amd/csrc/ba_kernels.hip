@@ -367,6 +367,142 @@ __device__ __noinline__ void pinv_sym3(double a00, double a01, double a02, doubl
   out[5] = i0 * v0[2] * v0[2] + i1 * v1[2] * v1[2] + i2 * v2[2] * v2[2];
 }
 
+// What one observation brings to its point: the point block bb (B, or minus the camera-centre
+// columns of A when no B is given), the weight w, bp = w bb and we = w (x_true - x_pred).
+struct ObsTerms {
+  double bb[6], bp[6], we[2];
+  double w00, w01, w10, w11;
+};
+
+__device__ inline void obs_terms(int64_t pos, const double* __restrict__ A, const double* __restrict__ B,
+                                 const double* __restrict__ xt, const double* __restrict__ xpred,
+                                 const double* __restrict__ wgt, ObsTerms& o) {
+  if (B) {
+    const double* b = B + 6 * pos;
+    const double2 b01 = ld2(b), b23 = ld2(b + 2), b45 = ld2(b + 4);
+    o.bb[0] = b01.x; o.bb[1] = b01.y; o.bb[2] = b23.x; o.bb[3] = b23.y; o.bb[4] = b45.x; o.bb[5] = b45.y;
+  } else {
+    const double* ap = A + 14 * pos;
+    const double2 a45 = ld2(ap + 4), a1213 = ld2(ap + 12);
+    o.bb[0] = -a45.x; o.bb[1] = -a45.y; o.bb[2] = -ap[6]; o.bb[3] = -ap[11]; o.bb[4] = -a1213.x; o.bb[5] = -a1213.y;
+  }
+  const double2 xa = ld2(xt + 2 * pos), xb = ld2(xpred + 2 * pos);
+  const double e0 = xa.x - xb.x, e1 = xa.y - xb.y;
+  o.w00 = 1.0; o.w01 = 0.0; o.w10 = 0.0; o.w11 = 1.0;
+  if (wgt) {
+    const double* wp = wgt + 4 * pos;
+    o.w00 = wp[0]; o.w01 = wp[1]; o.w10 = wp[2]; o.w11 = wp[3];
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    o.bp[q] = o.w00 * o.bb[q] + o.w01 * o.bb[3 + q];
+    o.bp[3 + q] = o.w10 * o.bb[q] + o.w11 * o.bb[3 + q];
+  }
+  o.we[0] = o.w00 * e0 + o.w01 * e1;
+  o.we[1] = o.w10 * e0 + o.w11 * e1;
+}
+
+// V^-1 (00 01 02 11 12 22) of the damped point block from the sums a[0..5] = B^T w B.
+__device__ inline void point_inverse(const double* a, double mu, double (&inv)[6]) {
+  const double v00 = a[0] + mu, v01 = a[1], v02 = a[2], v11 = a[3] + mu, v12 = a[4], v22 = a[5] + mu;
+  const double c00 = v11 * v22 - v12 * v12;
+  const double c01 = v02 * v12 - v01 * v22;
+  const double c02 = v01 * v12 - v02 * v11;
+  const double c11 = v00 * v22 - v02 * v02;
+  const double c12 = v01 * v02 - v00 * v12;
+  const double c22 = v00 * v11 - v01 * v01;
+  const double det = v00 * c00 + v01 * c01 + v02 * c02;
+  const double id = 1.0 / det;
+  inv[0] = c00 * id; inv[1] = c01 * id; inv[2] = c02 * id; inv[3] = c11 * id; inv[4] = c12 * id; inv[5] = c22 * id;
+  // (nearly) rank-deficient V_i - cond(V_i) beyond ~1e10, where the cofactor form has lost its
+  // digits, or det <= 0: the pseudo-inverse, as the reference's pinv gives it
+  const double tr = (v00 + v11 + v22) * (1.0 / 3.0);
+  if (!(det > 1e-10 * tr * tr * tr)) pinv_sym3(v00, v01, v02, v11, v12, v22, inv);
+}
+
+// A point with more observations than a workgroup has lanes (its range holds this point alone):
+// the lanes stride over the observations twice - sums for V_i and eps_b_i, reduced through LDS in a
+// fixed order, then g and the k (k + 1) / 2 couplings, the second observation's terms re-read.
+__device__ __noinline__ void point_long(int t, int p0, int s0, int ns, const int32_t* __restrict__ perm,
+                                        const int32_t* __restrict__ tp_ptr, const int32_t* __restrict__ pair_entry,
+                                        const double* __restrict__ A, const double* __restrict__ B,
+                                        const double* __restrict__ xt, const double* __restrict__ xpred,
+                                        const double* __restrict__ wgt, double mu, int fold_u,
+                                        double* __restrict__ Vinv, double* __restrict__ eps_b, double* __restrict__ g,
+                                        double* __restrict__ T, double* sRed /* 256 x 9 */) {
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s = t; s < ns; s += 256) {
+    ObsTerms o;
+    obs_terms(perm[s0 + s], A, B, xt, xpred, wgt, o);
+    acc[0] += o.bb[0] * o.bp[0] + o.bb[3] * o.bp[3];
+    acc[1] += o.bb[0] * o.bp[1] + o.bb[3] * o.bp[4];
+    acc[2] += o.bb[0] * o.bp[2] + o.bb[3] * o.bp[5];
+    acc[3] += o.bb[1] * o.bp[1] + o.bb[4] * o.bp[4];
+    acc[4] += o.bb[1] * o.bp[2] + o.bb[4] * o.bp[5];
+    acc[5] += o.bb[2] * o.bp[2] + o.bb[5] * o.bp[5];
+    acc[6] += o.bb[0] * o.we[0] + o.bb[3] * o.we[1];
+    acc[7] += o.bb[1] * o.we[0] + o.bb[4] * o.we[1];
+    acc[8] += o.bb[2] * o.we[0] + o.bb[5] * o.we[1];
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) sRed[9 * t + q] = acc[q];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) sRed[9 * t + q] += sRed[9 * (t + o) + q];
+    }
+    __syncthreads();
+  }
+  double a[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) a[q] = sRed[q];
+  double iv[6];
+  point_inverse(a, mu, iv);  // every lane, same numbers
+  const double z0 = iv[0] * a[6] + iv[1] * a[7] + iv[2] * a[8];
+  const double z1 = iv[1] * a[6] + iv[3] * a[7] + iv[4] * a[8];
+  const double z2 = iv[2] * a[6] + iv[4] * a[7] + iv[5] * a[8];
+  if (t == 0) {
+    double* vo = Vinv + 9 * (int64_t)p0;
+    vo[0] = iv[0]; vo[1] = iv[1]; vo[2] = iv[2];
+    vo[3] = iv[1]; vo[4] = iv[3]; vo[5] = iv[4];
+    vo[6] = iv[2]; vo[7] = iv[4]; vo[8] = iv[5];
+    double* eo = eps_b + 3 * (int64_t)p0;
+    eo[0] = a[6]; eo[1] = a[7]; eo[2] = a[8];
+  }
+  const int64_t k = ns;
+  for (int ai = t; ai < ns; ai += 256) {
+    ObsTerms o;
+    const int64_t pos = perm[s0 + ai];
+    obs_terms(pos, A, B, xt, xpred, wgt, o);
+    st2(g + 2 * pos, o.we[0] - (o.bp[0] * z0 + o.bp[1] * z1 + o.bp[2] * z2),
+        o.we[1] - (o.bp[3] * z0 + o.bp[4] * z1 + o.bp[5] * z2));
+    const double h00 = o.bp[0] * iv[0] + o.bp[1] * iv[1] + o.bp[2] * iv[2];
+    const double h01 = o.bp[0] * iv[1] + o.bp[1] * iv[3] + o.bp[2] * iv[4];
+    const double h02 = o.bp[0] * iv[2] + o.bp[1] * iv[4] + o.bp[2] * iv[5];
+    const double h10 = o.bp[3] * iv[0] + o.bp[4] * iv[1] + o.bp[5] * iv[2];
+    const double h11 = o.bp[3] * iv[1] + o.bp[4] * iv[3] + o.bp[5] * iv[4];
+    const double h12 = o.bp[3] * iv[2] + o.bp[4] * iv[4] + o.bp[5] * iv[5];
+    int64_t ts = (int64_t)tp_ptr[p0] + (int64_t)ai * k - (int64_t)ai * (ai - 1) / 2;
+    for (int b = ai; b < ns; ++b, ++ts) {
+      ObsTerms ob;
+      if (b == ai)
+        ob = o;
+      else
+        obs_terms(perm[s0 + b], A, B, xt, xpred, wgt, ob);
+      const double* q = ob.bp;
+      double* out = T + 4 * (int64_t)pair_entry[ts];
+      double t00 = h00 * q[0] + h01 * q[1] + h02 * q[2], t01 = h00 * q[3] + h01 * q[4] + h02 * q[5];
+      double t10 = h10 * q[0] + h11 * q[1] + h12 * q[2], t11 = h10 * q[3] + h11 * q[4] + h12 * q[5];
+      if (fold_u && b == ai) {
+        t00 -= o.w00; t01 -= o.w01; t10 -= o.w10; t11 -= o.w11;
+      }
+      st2(out, t00, t01);
+      st2(out + 2, t10, t11);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // per-point stage: V_i, V_i^-1, eps_b_i, then per observation g = w (eps - B V^-1 eps_b) and per
 // observation pair (a <= b) of the point the 2x2 coupling T_ab = (wB)_a V^-1 (wB)_b^T.
@@ -391,6 +527,10 @@ __global__ __launch_bounds__(256) void k_point(
   __syncthreads();
   const int s0 = sPtr[0];
   const int ns = sPtr[np] - s0;
+  if (ns > kGroupSlots) {  // one point with more observations than lanes (same for the whole workgroup)
+    point_long(t, p0, s0, ns, perm, tp_ptr, pair_entry, A, B, xt, xpred, wgt, mu, fold_u, Vinv, eps_b, g, T, sCon);
+    return;
+  }
   if (t < np)
     for (int s = sPtr[t]; s < sPtr[t + 1]; ++s) sLp[s - s0] = t;
 
@@ -444,24 +584,9 @@ __global__ __launch_bounds__(256) void k_point(
 #pragma unroll
       for (int q = 0; q < 9; ++q) a[q] += sCon[9 * s + q];
     }
-    const double v00 = a[0] + mu, v01 = a[1], v02 = a[2], v11 = a[3] + mu, v12 = a[4], v22 = a[5] + mu;
-    const double c00 = v11 * v22 - v12 * v12;
-    const double c01 = v02 * v12 - v01 * v22;
-    const double c02 = v01 * v12 - v02 * v11;
-    const double c11 = v00 * v22 - v02 * v02;
-    const double c12 = v01 * v02 - v00 * v12;
-    const double c22 = v00 * v11 - v01 * v01;
-    const double det = v00 * c00 + v01 * c01 + v02 * c02;
-    const double id = 1.0 / det;
-    double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id, i11 = c11 * id, i12 = c12 * id, i22 = c22 * id;
-    // (nearly) rank-deficient V_i - cond(V_i) beyond ~1e10, where the cofactor form has lost its
-    // digits, or det <= 0: the pseudo-inverse, as the reference's pinv gives it
-    const double tr = (v00 + v11 + v22) * (1.0 / 3.0);
-    if (!(det > 1e-10 * tr * tr * tr)) {
-      double pi[6];
-      pinv_sym3(v00, v01, v02, v11, v12, v22, pi);
-      i00 = pi[0]; i01 = pi[1]; i02 = pi[2]; i11 = pi[3]; i12 = pi[4]; i22 = pi[5];
-    }
+    double iv[6];
+    point_inverse(a, mu, iv);
+    const double i00 = iv[0], i01 = iv[1], i02 = iv[2], i11 = iv[3], i12 = iv[4], i22 = iv[5];
     // V^-1 and V^-1 eps_b of the point go where the contributions of its first observation were:
     // only this thread has read them (a point without observations has no such place and nobody
     // reads its record)
@@ -980,6 +1105,62 @@ __global__ __launch_bounds__(256) void k_back_substitute(
   __syncthreads();
   const int s0 = sPtr[0];
   const int ns = sPtr[np] - s0;
+  if (ns > kGroupSlots) {
+    // one point with more observations than lanes: the lanes stride over them, sums through LDS
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int s = t; s < ns; s += 256) {
+      const int64_t pos = perm[s0 + s];
+      const double* dj = da + 7 * (int64_t)slot_cam[s0 + s];
+      const double* ap = A + 14 * pos;
+      double h0 = 0.0, h1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        h0 += ap[q] * dj[q];
+        h1 += ap[7 + q] * dj[q];
+      }
+      double w00 = 1.0, w01 = 0.0, w10 = 0.0, w11 = 1.0;
+      if (wgt) {
+        const double* wp = wgt + 4 * pos;
+        w00 = wp[0]; w01 = wp[1]; w10 = wp[2]; w11 = wp[3];
+      }
+      const double k0 = w00 * h0 + w01 * h1, k1 = w10 * h0 + w11 * h1;
+      if (B) {
+        const double* b = B + 6 * pos;
+        a0 += b[0] * k0 + b[3] * k1;
+        a1 += b[1] * k0 + b[4] * k1;
+        a2 += b[2] * k0 + b[5] * k1;
+      } else {
+        a0 += -ap[4] * k0 - ap[11] * k1;
+        a1 += -ap[5] * k0 - ap[12] * k1;
+        a2 += -ap[6] * k0 - ap[13] * k1;
+      }
+    }
+    sV[3 * t] = a0; sV[3 * t + 1] = a1; sV[3 * t + 2] = a2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (t < o) {
+        sV[3 * t] += sV[3 * (t + o)];
+        sV[3 * t + 1] += sV[3 * (t + o) + 1];
+        sV[3 * t + 2] += sV[3 * (t + o) + 2];
+      }
+      __syncthreads();
+    }
+    if (t == 0) {
+      const int64_t p = p0;
+      const double r0 = eps_b[3 * p] - sV[0], r1 = eps_b[3 * p + 1] - sV[1], r2 = eps_b[3 * p + 2] - sV[2];
+      const double* v = Vinv + 9 * p;
+      const double d0 = v[0] * r0 + v[1] * r1 + v[2] * r2;
+      const double d1 = v[3] * r0 + v[4] * r1 + v[5] * r2;
+      const double d2 = v[6] * r0 + v[7] * r1 + v[8] * r2;
+      db[3 * p] = d0; db[3 * p + 1] = d1; db[3 * p + 2] = d2;
+      if (Xupd) {
+        Xupd[3 * p] += x_step * d0;
+        Xupd[3 * p + 1] += x_step * d1;
+        Xupd[3 * p + 2] += x_step * d2;
+      }
+    }
+    return;
+  }
   if (t < ns) {
     const int64_t pos = perm[s0 + t];
     const double* dj = da + 7 * (int64_t)slot_cam[s0 + t];

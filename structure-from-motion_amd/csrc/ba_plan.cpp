@@ -118,15 +118,14 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
       slot_cam[s] = cam_idx[i];
     }
   }
-  int32_t kmax = 0;
+  int32_t kshort = 0;  // kshort: the most views among the points that fit one workgroup range
   for (int32_t i = 0; i < n; ++i) {
     const int32_t k = pt_ptr[i + 1] - pt_ptr[i];
-    kmax = std::max(kmax, k);
+    if (k <= kGroupSlots) kshort = std::max(kshort, k);
     if (check)
       for (int32_t s = pt_ptr[i] + 1; s < pt_ptr[i + 1]; ++s)
         if (slot_cam[s] == slot_cam[s - 1]) return SFM_BA_ENONUNIQUE;
   }
-  if (kmax > SFM_BA_MAX_VIEWS || kmax > kGroupSlots) return SFM_BA_ETOOBIG;
   if (N * 112 >= (int64_t(1) << 32)) return SFM_BA_ETOOBIG;  // 32-bit byte offsets into A
 
   sfm_ba_plan* p = new (std::nothrow) sfm_ba_plan();
@@ -137,19 +136,23 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
 
   // ---- per-point pair slots and workgroup ranges ----
   // A point takes max(k, 1) units; it opens a new workgroup range when its first unit falls into
-  // another window of kGroupSlots - kmax + 1 units than its predecessor's.  A range then holds at
+  // another window of kGroupSlots - kshort + 1 units than its predecessor's.  A range then holds at
   // most kGroupSlots observations and at most kGroupSlots points, and the rule needs no sequential
-  // pass (the device builder applies it with a prefix sum).
+  // pass (the device builder applies it with a prefix sum).  A point seen by more than kGroupSlots
+  // cameras takes one unit and a range of its own (the kernels stride over its observations).
   std::vector<int32_t> tp_ptr(n + 1, 0), grp_pt;
   int64_t pairs = 0;
   {
-    const int32_t window = kGroupSlots - std::max(kmax, 1) + 1;
+    const int32_t window = kGroupSlots - std::max(kshort, 1) + 1;
     int64_t unit = 0, prev_unit = 0;
+    bool prev_long = false;
     for (int32_t i = 0; i < n; ++i) {
       const int32_t k = pt_ptr[i + 1] - pt_ptr[i];
-      if (i == 0 || unit / window != prev_unit / window) grp_pt.push_back(i);
+      const bool is_long = k > kGroupSlots;
+      if (i == 0 || unit / window != prev_unit / window || is_long || prev_long) grp_pt.push_back(i);
       prev_unit = unit;
-      unit += std::max(k, 1);
+      prev_long = is_long;
+      unit += is_long ? 1 : std::max(k, 1);
       tp_ptr[i] = (int32_t)pairs;
       pairs += (int64_t)k * (k + 1) / 2;
       // 32-bit byte offsets into T, counted from the start of g that precedes it in the workspace

@@ -40,7 +40,7 @@ struct Scratch {
 // statistics the host reads back between phases
 enum Stat {
   ST_MAX_CAM = 0, ST_MAX_PT, ST_NEGATIVE, ST_CAM_UNSORTED, ST_KMAX, ST_EMPTY_CAM, ST_EMPTY_PT, ST_NONUNIQUE,
-  ST_MAX_DIST, ST_SPAN_MAX, ST_COUNT
+  ST_MAX_DIST, ST_SPAN_MAX, ST_KSHORT, ST_COUNT
 };
 
 __global__ void k_idx_stats(const int32_t* __restrict__ cam, const int32_t* __restrict__ pt, int64_t N,
@@ -116,8 +116,9 @@ __global__ void k_point_counts(const int32_t* __restrict__ pt_cnt, int32_t n, in
   }
   const int32_t k = pt_cnt[i];
   pairs[i] = (int64_t)k * (k + 1) / 2;
-  units[i] = k > 0 ? k : 1;
+  units[i] = (k > 0 && k <= kGroupSlots) ? k : 1;  // a point with more views than a range holds gets a range of its own
   atomicMax(&stats[ST_KMAX], k);
+  if (k <= kGroupSlots) atomicMax(&stats[ST_KSHORT], k);
   if (k == 0) stats[ST_EMPTY_PT] = 1;
 }
 
@@ -141,10 +142,14 @@ __global__ void k_narrow(const int64_t* __restrict__ in, int32_t n, int32_t* __r
 
 // a point opens a workgroup range of the per-point kernels when its first unit falls into another
 // window of `window` units than its predecessor's (unit_ptr = prefix sum of max(k, 1))
-__global__ void k_group_flags(const int32_t* __restrict__ unit_ptr, int32_t n, int32_t window, int32_t* __restrict__ flag) {
+__global__ void k_group_flags(const int32_t* __restrict__ unit_ptr, const int32_t* __restrict__ pt_cnt, int32_t n,
+                              int32_t window, int32_t* __restrict__ flag) {
   const int32_t i = blockIdx.x * kT + threadIdx.x;
   if (i > n) return;
-  flag[i] = i < n && (i == 0 || unit_ptr[i] / window != unit_ptr[i - 1] / window) ? 1 : 0;
+  flag[i] = i < n && (i == 0 || unit_ptr[i] / window != unit_ptr[i - 1] / window || pt_cnt[i] > kGroupSlots ||
+                      pt_cnt[i - 1] > kGroupSlots)
+                ? 1
+                : 0;
 }
 
 __global__ void k_group_fill(const int32_t* __restrict__ flag, const int32_t* __restrict__ gid, int32_t n,
@@ -425,7 +430,7 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
     return SFM_BA_OK;
   };
   {
-    int32_t init[ST_COUNT] = {-1, -1, 0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t init[ST_COUNT] = {-1, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     SFMBA_HIP(hipMemcpyAsync(d_stats, init, sizeof(init), hipMemcpyHostToDevice, st));
     SFMBA_HIP(hipStreamSynchronize(st));  // `init` leaves scope
   }
@@ -475,7 +480,6 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
     if (m_hint <= 0 && h[ST_EMPTY_CAM]) return SFM_BA_EMISSING_VIEW;
     if (n_hint <= 0 && h[ST_EMPTY_PT]) return SFM_BA_EMISSING_POINT;
   }
-  const int32_t kmax = h[ST_KMAX];
 
   // ---- observations sorted by (point, camera) ----
   const int cam_bits = bits_for(m), pt_bits = bits_for(n);
@@ -501,7 +505,6 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
   if (check && h[ST_NONUNIQUE]) return SFM_BA_ENONUNIQUE;
   const int32_t span_max = h[ST_SPAN_MAX];
   const bool empty_point = h[ST_EMPTY_PT] != 0;
-  if (kmax > SFM_BA_MAX_VIEWS || kmax > kGroupSlots) return SFM_BA_ETOOBIG;
   if (N * 112 >= (int64_t(1) << 32)) return SFM_BA_ETOOBIG;  // 32-bit byte offsets into A
   // 32-bit byte offsets into T, counted from the start of g that precedes it in the workspace
   if (N * 16 + 256 + (pairs + kPairPad) * 32 >= (int64_t(1) << 32)) return SFM_BA_ETOOBIG;
@@ -517,8 +520,8 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
     int32_t *flag, *gid;
     SFMBA_HIP(scratch.get(&flag, n + 1));
     SFMBA_HIP(scratch.get(&gid, n + 1));
-    const int32_t window = kGroupSlots - std::max(kmax, 1) + 1;
-    k_group_flags<<<blocks_for(n + 1), kT, 0, st>>>(unit_ptr, n, window, flag);
+    const int32_t window = kGroupSlots - std::max(h[ST_KSHORT], 1) + 1;
+    k_group_flags<<<blocks_for(n + 1), kT, 0, st>>>(unit_ptr, pt_cnt, n, window, flag);
     SFMBA_TRY(scan_exclusive(flag, gid, n + 1, scratch, st));
     int32_t n_groups = 0;
     SFMBA_HIP(hipMemcpyAsync(&n_groups, gid + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));

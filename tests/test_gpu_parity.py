@@ -319,25 +319,28 @@ def test_ladybug_scale_against_oracle(ba, visibility):
     assert relerr(prob.points(), X) < 1e-8
 
 
-def test_maximum_views_and_ragged_shapes(ba):
-    """Edge shapes of the index structures against the CPU oracle: one point seen by 256 cameras
-    (SFM_BA_MAX_VIEWS: the point fills a workgroup's range and its block list has 32 896 pairs), points
-    with a single observation, camera counts that are not multiples of anything; 257 views are
-    refused with the library's too-big status."""
+@pytest.mark.parametrize("m,where", [(256, "device"), (257, "device"), (257, "host"), (700, "device")])
+def test_maximum_views_and_ragged_shapes(ba, m, where):
+    """Edge shapes of the index structures against the CPU oracle: one point seen by every camera -
+    256 (the point fills a workgroup's range of the per-point kernels; its block list has 32 896 pairs),
+    257 and 700 (more observations than a range holds: the point gets a range of its own and the lanes
+    stride over its observations; the reference's ``Indices`` has no limit,
+    /root/reference/src/sparse_ba.py:58-97) - next to points with a single observation and camera
+    counts that are not multiples of anything."""
     from oracle import ba_oracle as orc
-    from sfm_amd import _lib, synthetic
-    from sfm_amd.device import DeviceProblem
+    from sfm_amd import synthetic
+    from sfm_amd.device import DeviceProblem, Plan
 
     rng = np.random.default_rng(4)
-    m, n = 256, 40
+    n = 40
     K = synthetic.K_DEFAULT
     X_gt = rng.uniform(-1, 1, size=(n, 3)) + np.array([0, 0, 8.0])
     R_gt = synthetic.rodrigues(rng.normal(0, 0.05, size=(m, 3)))
     T_gt = -np.einsum("mij,mj->mi", R_gt, rng.normal(0, 0.3, size=(m, 3)))
     pt, cam = [], []
     for i in range(n):
-        if i == 0:
-            cams = np.arange(m)                      # the maximum
+        if i in ((0, 21) if m < 700 else (0, 21, 22, 30, 39)):
+            cams = np.arange(m)                      # every camera (neighbours and the last point among them)
         elif i < 8:
             cams = rng.choice(m, size=1)             # single observations
         else:
@@ -345,7 +348,14 @@ def test_maximum_views_and_ragged_shapes(ba):
         pt += [i] * len(cams)
         cam += list(cams)
     p = synthetic.observe_and_perturb(rng, K, R_gt, T_gt, X_gt, np.asarray(pt), np.asarray(cam))
-    prob = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true, check=False, n_cams=m)
+    host, dev = Plan(p.cam_idx, p.pt_idx, where="host"), Plan(p.cam_idx, p.pt_idx, where="device")
+    for f in Plan.FIELDS:
+        assert np.array_equal(host.read(f), dev.read(f)), f
+    grp = host.read("grp_pt")
+    counts = np.bincount(p.pt_idx, minlength=n)
+    for a, b in zip(grp[:-1], grp[1:]):
+        assert b > a and (counts[a:b].sum() <= 256 or b - a == 1)
+    prob = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true, check=False, n_cams=m, plan_where=where)
     R, T, X = p.R.copy(), p.T.copy(), p.X.copy()
     c_ref, da_ref, db_ref = orc.gn_iteration_arrays(p.K, R, T, X, p.cam_idx, p.pt_idx, p.x_true)
     prob.iterate_async()
@@ -354,12 +364,14 @@ def test_maximum_views_and_ragged_shapes(ba):
     assert abs(c - c_ref) <= 1e-8 * c_ref
     assert relerr(prob.delta_b.cpu().numpy(), db_ref) < 1e-6
     assert relerr(prob.points(), X) < 1e-8
-
-    # 257 views of one point
-    cam2 = np.concatenate([np.arange(257), np.arange(257)]).astype(np.int32)
-    pt2 = np.concatenate([np.zeros(257), np.ones(257)]).astype(np.int32)
-    with pytest.raises(_lib.SfmBaError):
-        ba.dev.Plan(cam2, pt2)
+    # the stages with every by-product and B handed over take the same long-point path
+    prob2 = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true, check=False, n_cams=m)
+    prob2.camera_prepare()
+    prob2.jacobian()
+    prob2.assemble(0.5)
+    prob2.solve()
+    prob2.back_substitute()
+    assert relerr(prob2.delta_b.cpu().numpy(), db_ref) < 1e-6
 
 
 def test_point_block_taken_from_A(ba):
