@@ -23,8 +23,8 @@ constexpr int kPairPartStride = 56;  // doubles per partial result of a split bl
 // of a wave then owns one observation or none, 8 points per step.
 constexpr int kFzLanesPerPoint = 8;  // lanes (= slot positions of the table) per point
 constexpr int kFzMaxPmax = 1024;     // longest range of points one wave walks (and with it: runs per range)
-constexpr int kFzSlotRec = 40;       // doubles per camera slot behind a partial's tiles: 28 (upper triangle of
-                                     // sum A^T A) + 7 (sum A^T g), padded
+constexpr int kFzSlotSums = 35;      // per-camera-slot sums behind a partial's tiles: 28 (upper triangle of
+                                     // sum A^T A) + 7 (sum A^T g); 7 more per extra row
 struct FzShape {
   int slots;  // camera slots of a window: 4 .. 8
   int group;  // consecutive first-cameras that share a window: slots - span + 1
@@ -43,11 +43,13 @@ inline bool fz_shape(int32_t n, int32_t span_max, bool empty_point, FzShape* o) 
 // runs must be long enough for their fixed cost (one partial result each) to be small
 inline bool fz_worthwhile(int32_t n, int32_t n_runs) { return (int64_t)n_runs * 24 <= (int64_t)n + 1536; }
 // the 7 * slots rows of a window: 16 per row tile of the matrix cores, the rest ("extra rows") summed by the lanes
-__host__ __device__ inline int fz_row_tiles(int slots) { return slots <= 5 ? 2 : (slots <= 7 ? 3 : 4); }
-__host__ __device__ inline int fz_extra_rows(int slots) { return slots == 5 ? 3 : (slots == 7 ? 1 : 0); }
-// doubles of one partial result: lower-triangle tiles (16 x 16), extra rows (64 each), 8 slot records
+__host__ __device__ inline int fz_row_tiles(int slots) { return slots <= 4 ? 2 : (slots <= 7 ? 3 : 4); }
+__host__ __device__ inline int fz_extra_rows(int slots) { return slots == 7 ? 1 : 0; }
+// doubles of one partial result: lower-triangle tiles (16 x 16), then the per-slot sums as
+// [value][slot] (value i of slot s at 8 i + s: 28 of U, 7 of e, 7 per extra row), rounded up to whole
+// 256-byte units
 __host__ __device__ constexpr int64_t fz_part_stride_c(int tiles, int extra) {
-  return (int64_t)(tiles * (tiles + 1) / 2) * 256 + extra * 64 + 8 * kFzSlotRec;
+  return (int64_t)(tiles * (tiles + 1) / 2) * 256 + (((kFzSlotSums + 7 * extra) * 8 + 31) & ~31);
 }
 __host__ __device__ inline int64_t fz_part_stride(int slots) {
   return fz_part_stride_c(fz_row_tiles(slots), fz_extra_rows(slots));

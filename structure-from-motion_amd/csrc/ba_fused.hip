@@ -157,7 +157,11 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
   const int nr = rng_run[blockIdx.x + 1] - run0;
   int f0 = blockIdx.x * pmax, r0 = 0;  // first point of the step, its run (relative to run0)
   // slot table entry of this lane for a step that starts at point `first` in a run that ends before `lim`
-#define FZ_FETCH_POS(first, lim) (((first) + p) < (lim) ? slot_obs[kFzLanesPerPoint * (int64_t)((first) + p) + s] : -1)
+  // (a 32-bit index: the address is then the kernel argument plus a lane offset; as a 64-bit per-lane
+  // pointer it is kept in registers across the steps, spilled, and every reload of a spill waits for
+  // all loads in flight - the next step's operands)
+#define FZ_FETCH_POS(first, lim) \
+  (((first) + p) < (lim) ? slot_obs[(unsigned)(kFzLanesPerPoint * ((first) + p) + s)] : -1)
   // row of A (a_(0..13)), x_true (a_(14..15)) and x_pred (a_(16..17)) of observation `pos`; a lane
   // without an observation reads the row of zeros the launcher keeps in the workspace (selecting the
   // address keeps the loads unconditional, so that they land in the registers of av[] themselves)
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
 #define FZ_LIM(r) __builtin_amdgcn_readfirstlane(bnd[(r) + 1])
   // the first step's table entries do not need the boundaries: they are on their way meanwhile
   const int pt_first = f0 + p < n_pts ? f0 + p : n_pts - 1;
-  const int pos_raw = BLOCKED ? 0 : slot_obs[kFzLanesPerPoint * (int64_t)pt_first + s];
+  const int pos_raw = BLOCKED ? 0 : slot_obs[(unsigned)(kFzLanesPerPoint * pt_first + s)];
   int kfetch = BLOCKED ? rng_step[blockIdx.x] : 0;  // step whose block the next fetch reads
   for (int i = lane; i <= nr; i += 64) bnd[i] = run_pt0[run0 + i];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -386,42 +390,49 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
     {
       // ---- the run's partial result: tiles as they lie in the registers, the extra rows, the per-slot
       // sums; then everything starts from zero for the next run ----
+      // (every index below is rebuilt from a laundered copy of the lane id: values that stay live
+      // across the steps for the sake of this block end up in scratch memory, and a reload from there
+      // is followed by a wait for everything in flight - the stores issued just before included)
+      int fl = lane;
+      asm volatile("" : "+v"(fl));
+      const int fli = fl & 15, flk = fl >> 4;
       double* po = part + (int64_t)run * STRIDE;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) po[t * 256 + (lk + 4 * v) * 16 + li] = acc[t][v];
+        for (int v = 0; v < 4; ++v) po[t * 256 + (flk + 4 * v) * 16 + fli] = acc[t][v];
         acc[t] = d4_t{0.0, 0.0, 0.0, 0.0};
       }
+      FZ_STAMP(8);  // tiles of the run stored
       // the per-slot sums (28 + 7 + 7 E values per lane) are added over the 8 points through the
       // panel's LDS, 21 values at a time: lane l parks value j at [j][l], then lane (j, slot) adds the
       // eight entries [j][8 p + slot] in the order of p and stores the sum
-      constexpr int NV = 35 + 7 * E;
+      constexpr int NV = kFzSlotSums + 7 * E;
 #pragma unroll
       for (int c0 = 0; c0 < NV; c0 += 21) {
         const int cnt = NV - c0 < 21 ? NV - c0 : 21;
 #pragma unroll
         for (int j = 0; j < 21; ++j) {
           const int i = c0 + j;
-          if (i < NV) Zp[j * 64 + lane] = i < 28 ? u[i < 28 ? i : 0] : (i < 35 ? ev[i < 35 && i >= 28 ? i - 28 : 0] : xa[i >= 35 ? (i - 35) / 7 : 0][i >= 35 ? (i - 35) % 7 : 0]);
+          if (i < NV) Zp[j * 64 + fl] = i < 28 ? u[i < 28 ? i : 0] : (i < 35 ? ev[i < 35 && i >= 28 ? i - 28 : 0] : xa[i >= 35 ? (i - 35) / 7 : 0][i >= 35 ? (i - 35) % 7 : 0]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        FZ_STAMP(9);  // sums parked in LDS
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          const int o = 64 * k + lane;
+          const int o = 64 * k + fl;
           if (o < 8 * cnt) {
-            const int j = o >> 3, ss = o & 7, i = c0 + j;
+            const int j = o >> 3, ss = o & 7;
             const double* z = Zp + j * 64 + ss;
             double sum = z[0];
 #pragma unroll
             for (int pp = 1; pp < 8; ++pp) sum += z[8 * pp];
-            const int dst = i < 35 ? NT * 256 + E * 64 + ss * kFzSlotRec + i
-                                   : NT * 256 + ((i - 35) / 7) * 64 + 8 * ss + (i - 35) % 7;
-            po[dst] = sum;
+            po[NT * 256 + 8 * c0 + o] = sum;  // value i of slot ss at [i][ss]: whole lines per store
           }
         }
+        FZ_STAMP(10);  // sums added and their stores issued
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
@@ -504,12 +515,12 @@ __global__ __launch_bounds__(64) void k_fused_finish(const int32_t* __restrict__
         const int ti = row >> 4, tj = col >> 4;
         v = pb[(ti * (ti + 1) / 2 + tj) * 256 + (row & 15) * 16 + (col & 15)];
       } else {
-        v = pb[nt * 256 + (row - 16 * T) * 64 + 8 * (col / 7) + col % 7];
+        v = pb[nt * 256 + (35 + 7 * (row - 16 * T) + col % 7) * 8 + col / 7];
       }
-      if (j == k) v = pb[nt * 256 + E * 64 + sj * kFzSlotRec + uidx] - v;
+      if (j == k) v = pb[nt * 256 + uidx * 8 + sj] - v;
       sum += v;
     } else {
-      sum += pb[nt * 256 + E * 64 + sj * kFzSlotRec + 28 + (t - 49)];
+      sum += pb[nt * 256 + (28 + (t - 49)) * 8 + sj];
     }
   }
   const int64_t ld = 7 * (int64_t)m;
@@ -622,13 +633,18 @@ int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* x
         FZ_LAUNCH4(W, T, E, 2, false);        \
     }                                         \
   } while (0)
-    static const int wps = [] {
+    // waves per SIMD the kernel is compiled for: two (256 registers each) hide memory latency better,
+    // unless the variant then spills - a reload from scratch memory waits for every load in flight.
+    // The 5-slot variant (three rows behind the tiles: 21 more accumulators) spills at 256 registers
+    // and runs 2.3 x faster with 512 (1 800 cameras x 1 M points: 319 us against 737 us).
+    static const int wps_env = [] {
       const char* v = getenv("SFM_BA_FZ_WPS");
-      return v && v[0] == '1' ? 1 : 2;
+      return v && (v[0] == '1' || v[0] == '2') ? v[0] - '0' : 0;
     }();
+    const int wps = wps_env ? wps_env : 2;
     switch (p->fz_slots) {
       case 4: FZ_LAUNCH(4, 2, 0); break;
-      case 5: FZ_LAUNCH(5, 2, 3); break;
+      case 5: FZ_LAUNCH(5, 3, 0); break;
       case 6: FZ_LAUNCH(6, 3, 0); break;
       case 7: FZ_LAUNCH(7, 3, 1); break;
       default: FZ_LAUNCH(8, 4, 0); break;
@@ -640,8 +656,8 @@ int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* x
   {
     unsigned long long h[16];
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fz_stamps), sizeof(h));
-    fprintf(stderr, "fz stamps (previous launch): setup %llu operands %llu valu %llu z %llu panel %llu fetch %llu mfma %llu flush %llu\n",
-            h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    fprintf(stderr, "fz stamps (previous launch): setup %llu operands %llu valu %llu z %llu panel %llu fetch %llu mfma %llu tiles out %llu sums parked %llu added %llu rest %llu\n",
+            h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[10], h[7]);
     memset(h, 0, sizeof(h));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fz_stamps), h, sizeof(h));
   }

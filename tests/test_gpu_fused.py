@@ -23,7 +23,7 @@ def _problem(m, n, k, seed=0):
 CASES = [
     (30, 6000, (5, 7), 7, 1),    # 3 row tiles + 1 extra row
     (16, 2000, 8, 8, 1),         # 4 row tiles
-    (40, 9000, (3, 5), 5, 1),    # 2 row tiles + 3 extra rows
+    (40, 9000, (3, 5), 5, 1),    # 3 row tiles (35 of their 48 rows used)
     (25, 4000, 6, 6, 1),         # 3 row tiles
     (64, 20001, (2, 4), 4, 1),   # 2 row tiles
     (50, 8000, (2, 3), 4, 2),    # two first-cameras per window
