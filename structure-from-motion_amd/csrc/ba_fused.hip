@@ -122,13 +122,16 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 // plan: 8 pieces of 1 KiB, piece q holding 16 bytes per lane: the row of A in pieces 0..6, the
 // residual x_true - x_pred in piece 7), every load a whole contiguous KiB; otherwise they are
 // gathered row by row from A, x_true and x_pred in the caller's order through the slot table.
+// what lanes of k_fused_runs without an observation read as their operands: zeros, never written
+__device__ __align__(256) const double g_fz_zero_row[32] = {0.0};
+
 template <int W, int T, int E, int WPS, bool BLOCKED>  // WPS: waves per SIMD the register allocation leaves room for
 __global__ __launch_bounds__(64, WPS) void k_fused_runs(
     const int32_t* __restrict__ rng_run, const int32_t* __restrict__ run_pt0,
     const int32_t* __restrict__ slot_obs, const double* __restrict__ A,
     const double* __restrict__ xt, const double* __restrict__ xp, const int32_t* __restrict__ rng_step,
     const double2* __restrict__ Ab, double mu, double* __restrict__ Vinv,
-    double* __restrict__ eps_b, double* __restrict__ part, const double* __restrict__ zero_row, int pmax,
+    double* __restrict__ eps_b, double* __restrict__ part, int pmax,
     int n_pts) {
   static_assert(16 * T + E >= 7 * W && 16 * T <= 7 * W + 15, "tiles and extra rows must cover the window");
   static_assert(E == 0 || (16 * T) / 7 == (16 * T + E - 1) / 7, "the extra rows belong to one camera slot");
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
   __shared__ __attribute__((aligned(16))) double Zp[24 * KS];  // [K column = 3 point + q][8 slot + r]
   __shared__ int bnd[kFzMaxPmax + 1];  // first point of every run of this wave's range, and the range's end
   const int lane = threadIdx.x;
+  const double* zero_row = g_fz_zero_row;
   const int p = lane >> 3, s = lane & 7;
   const int li = lane & 15, lk = lane >> 4;
   // panel offset of dense row 16 t + li for the operand reads (rows past the window: a zero entry)
@@ -610,15 +614,12 @@ int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* x
   double* part = reinterpret_cast<double*>(base + p->ws_fpart);
   double* kpart = reinterpret_cast<double*>(base + p->ws_fkey);
   const int64_t stride = fz_part_stride(p->fz_slots);
-  // lanes of k_fused_runs without an observation read their operands from here
-  const double* zero_row = reinterpret_cast<const double*>(base + p->ws_fzero);
-  SFMBA_HIP(hipMemsetAsync(base + p->ws_fzero, 0, 256, st));
   {
     ProfScope ps(KID_FUSED_RUNS, st);
 #define FZ_LAUNCH4(W, T, E, WPS, BL)                                                                             \
   hipLaunchKernelGGL((k_fused_runs<W, T, E, WPS, BL>), dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0, \
                      p->d_slot_obs, A, xt, xp, p->d_rng_step, reinterpret_cast<const double2*>(steps), mu, Vinv,    \
-                     eps_b, part, zero_row, p->fz_pmax, p->n)
+                     eps_b, part, p->fz_pmax, p->n)
 #define FZ_LAUNCH(W, T, E)                    \
   do {                                        \
     if (steps) {                              \
