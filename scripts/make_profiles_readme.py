@@ -19,21 +19,22 @@ def bench(name):
 
 rows = [("default", "c4_500x300k banded (the `bench.py` default)"), ("c4_500x300k_uniform", "c4_500x300k uniform"),
         ("ladybug50_banded", "ladybug50 banded"), ("ladybug50_uniform", "ladybug50 uniform"),
-        ("venice1800_banded", "venice1800 banded")]
+        ("venice1800_banded", "venice1800 banded"), ("venice1800_uniform", "venice1800 uniform (dense S, 12 600 unknowns)")]
 out = [f"# profiles — round {tag[1:]} evidence (MI355X, one GPU)", "",
        "Produced by `bash scripts/gpu_evidence.sh <tag>` on the GPU box; this file is generated from the files next to it",
        "by `scripts/make_profiles_readme.py`.", "",
        "## Bench lines (`bench.py`, 10 timed Gauss-Newton iterations after 3 warm-up iterations)", "",
-       "| workload | cameras x points x observations | ms/iteration (with / without event records) | observations/s | reduced solve ms (path) | Jacobian / assembly / back-substitution, algorithmic GB/s |",
-       "|---|---|---|---|---|---|"]
+       "GB/s price the bytes the loop has to move (136 / 152 / 120 per observation: B is read out of A and never written).", "",
+       "| workload | cameras x points x observations | assembly | ms/iteration (with / without event records) | observations/s | reduced solve ms (path) | Jacobian / assembly / back-substitution, GB/s |",
+       "|---|---|---|---|---|---|---|"]
 for key, label in rows:
     d = bench(key)
     if d is None:
         continue
     g = d["roofline"]["groups"]
     c = d["config"]
-    out.append("| %s | %d x %d x %d | %.3f / %.3f | %.3g | %.3f (%s) | %.0f / %.0f / %.0f |" % (
-        label, c["cameras"], c["points"], c["observations"], d["ms_per_step"], d["ms_per_step_without_events"],
+    out.append("| %s | %d x %d x %d | %s | %.3f / %.3f | %.3g | %.3f (%s) | %.0f / %.0f / %.0f |" % (
+        label, c["cameras"], c["points"], c["observations"], c.get("assembly", ""), d["ms_per_step"], d["ms_per_step_without_events"],
         d["value"], d["solve"]["ms"], d["solve"].get("path", "blocked Cholesky"), g["jacobian"]["GBps"],
         g["assembly"]["GBps"], g["back_substitution"]["GBps"]))
 d = bench("default")
@@ -41,9 +42,10 @@ if d is not None:
     r = d["roofline"]
     out += ["", "## Default bench line: roofline and CPU baseline", "",
             f"* dominant HBM-bound stage: {r['kernel']}",
-            "* algorithmic bytes per iteration %.1f MB -> achieved %.0f GB/s = %.1f %% of the %.0f GB/s HBM peak" % (
+            "* algorithmic bytes per iteration %.1f MB -> achieved %.0f GB/s = %.1f %% of the %.0f GB/s HBM peak"
+            " (with B priced as a materialised array: %.0f GB/s = %.1f %%)" % (
                 r["groups"][max(r["groups"], key=lambda k: r["groups"][k]["ms"])]["bytes"] / 1e6, r["achieved"],
-                100 * r["frac"], r["peak"]),
+                100 * r["frac"], r["peak"], r.get("achieved_with_B", 0.0), 100 * r.get("frac_with_B", 0.0)),
             "* measured HBM traffic of that stage (PMC, below): %s" % (
                 "%.1f MB per iteration" % (r["traffic"] / 1e6) if r.get("traffic") else "not collected for this line"),
             ]
@@ -53,6 +55,13 @@ if d is not None:
             ", measured traffic %.1f MB (%.0f GB/s)" % (g["traffic"] / 1e6, g["traffic_GBps"]) if g.get("traffic") else ""))
     if r.get("note"):
         out.append("* note: " + r["note"])
+    u = d.get("uniform_visibility")
+    if u:
+        ug = u["groups"]
+        out.append("* same workload, uniform visibility (sub-record of the same line): %.3f ms per iteration; Jacobian %.1f us, "
+                   "assembly %.1f us (%s), back-substitution %.1f us, solve %.3f ms (%s)" % (
+                       u["ms_per_step"], 1e3 * ug["jacobian"]["ms"], 1e3 * ug["assembly"]["ms"],
+                       "+".join(ug["assembly"]["kernels"]), 1e3 * ug["back_substitution"]["ms"], u["solve"]["ms"], u["solve"]["path"]))
     cb = d.get("cpu_baseline")
     if cb:
         out += ["* CPU baseline (`kind: %s`, %d BLAS threads): %.3g observations/s — %s" % (
@@ -67,6 +76,12 @@ if os.path.exists(summ):
             "passes of `bench.py` and the pass that times the small kernels: 33 iterations).", "", "```"]
     out += [line.rstrip()[:150] for line in open(summ)]
     out += ["```"]
+reh = bench("rehearsal_2ranks")
+if reh is not None:
+    out += ["", "## Two-rank rehearsal of the sharded bench on the one GPU (`SFM_BA_BENCH_BACKEND=gloo bench.py --gpus 2 --workload ladybug50 --scaling strong`)", "",
+            "* n_gpus %d, scaling %s, final cost %.12g (the one-rank line of the same workload: see `%s_bench_ladybug50_banded.json`);"
+            " the ranks share one device and exchange through host copies, so the time (%.3f ms per iteration) means nothing" % (
+                reh["n_gpus"], reh["scaling"], reh["final_cost"], tag, reh["ms_per_step"])]
 pmc = os.path.join(P, f"{tag}_pmc_traffic.json")
 if os.path.exists(pmc):
     doc = json.load(open(pmc))
@@ -106,10 +121,10 @@ for name, title in (("setup", "Handing a problem over as host arrays (`scripts/t
 out += ["", "## Files", "",
         f"* `{tag}_bench_*.json` — the JSON line of each bench run",
         f"* `{tag}_c4_banded_kernel_stats.csv`, `{tag}_c4_banded_kernel_summary.txt` — rocprofv3 kernel statistics of the default bench",
-        f"* `{tag}_c4_banded_pmc_fetch_size.txt`, `{tag}_c4_banded_pmc_write_size.txt`, `{tag}_pmc_traffic.json` — PMC passes",
+        f"* `{tag}_*_pmc_fetch_size.txt`, `{tag}_*_pmc_write_size.txt`, `{tag}_pmc_traffic.json` — PMC passes (default workload, the same with uniform visibility, venice1800 banded)",
         f"* `{tag}_triangulate.json`, `{tag}_pnp.json` — triangulation and PnP benchmark lines",
         f"* `{tag}_setup.txt`, `{tag}_dropin.txt` — host-side timings of plan build / uploads and of the drop-in call",
-        f"* `{tag}_c4_banded_baseline_kernel_stats.csv` — the first working version of this round (9.4 ms per iteration), for comparison",
+        "* `README_r01.md` and the `r01_*` files — the previous round's evidence, for comparison",
         ""]
 open(os.path.join(P, "README.md"), "w").write("\n".join(out))
 print("wrote profiles/README.md")

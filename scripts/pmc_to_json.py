@@ -13,7 +13,7 @@ import json, re, sys
 def parse(path, name):
     out = {}
     for line in open(path):
-        m = re.match(r"sfmba::(\w+)\s+%s=([0-9.e+-]+)\(n=(\d+)\)" % name, line.strip())
+        m = re.search(r"sfmba::(\w+)(?:<[^>]*>)?\s+%s=([0-9.e+-]+)\(n=(\d+)\)" % name, line.strip())
         if m:
             out[m.group(1)] = (float(m.group(2)), int(m.group(3)))
     return out
