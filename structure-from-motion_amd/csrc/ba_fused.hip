@@ -92,14 +92,6 @@ __device__ __forceinline__ double bcast8(double v, int s) {
   return (s >> 2) == (SX >> 2) ? t : o;
 }
 
-// sum over the 8 lanes that share lane & 7
-__device__ __forceinline__ double sum_over_points(double v) {
-  v += dpp64<0x128>(v);  // row_ror:8 = lane ^ 8 inside a row of 16
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
-}
-
 // 1 / sqrt(x): hardware estimate refined by three Newton steps (the estimate is good to roughly
 // single precision; the third step is there for margin).  No special cases: x is a positive pivot.
 __device__ __forceinline__ double rsqrt_nr(double x) {
@@ -115,8 +107,9 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 
 // W camera slots per window, rows 7 slot + r (dense: no padding rows between cameras); the first
 // 16 T rows go through the matrix cores, the E rows behind them are accumulated by the lanes
-// themselves (21 FMAs per row and step: cheaper than another row of tiles for E <= 3).
-//   W = 4: T 2, E 0 (28 rows)   W = 5: T 2, E 3 (35)   W = 6: T 3, E 0 (42)   W = 7: T 3, E 1 (49)
+// themselves (21 FMAs per row and step: cheaper than another row of tiles for one row; three such
+// rows for W = 5 on two row tiles cost 42 registers more than a third row of tiles and spilled).
+//   W = 4: T 2, E 0 (28 rows)   W = 5: T 3, E 0 (35)   W = 6: T 3, E 0 (42)   W = 7: T 3, E 1 (49)
 //   W = 8: T 4, E 0 (56)
 // BLOCKED: the operands come from the step blocks k_jacobian_steps wrote (block k = step k of the
 // plan: 8 pieces of 1 KiB, piece q holding 16 bytes per lane: the row of A in pieces 0..6, the
