@@ -1015,16 +1015,15 @@ __global__ __launch_bounds__(256) void k_bcr_update(int n, int np, int s, double
   if (t < SB) ek[i * NB + q * SB + t] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
 }
 
-// x_i = inv(L_i)^T (y_i - P_u^T x_u - P_d^T x_d) for the blocks eliminated at stride s
-__global__ __launch_bounds__(256) void k_bcr_back(int n, int np, int s, int j0, const double* __restrict__ Dk,
-                                                  const double* __restrict__ Pu, const double* __restrict__ Pd,
-                                                  double* __restrict__ ek, double* __restrict__ x_out) {
-  __shared__ double xu[NB], xd[NB], zv[NB];
-  __shared__ double part[4][NB];
+// x_i = inv(L_i)^T (y_i - P_u^T x_u - P_d^T x_d) for block i with neighbours iu, id (negative: none).
+// xu, xd, zv: 64 doubles of LDS each, part: 4 x 64.  All 256 threads.
+__device__ __forceinline__ void bcr_back_block(int n, int i, int iu, int id, const double* __restrict__ Dk,
+                                               const double* __restrict__ Pu, const double* __restrict__ Pd,
+                                               double* __restrict__ ek, double* __restrict__ x_out, double* xu,
+                                               double* xd, double* zv, double (*part)[NB]) {
   const int t = threadIdx.x;
   const int col = t & 63, rq = t >> 6;
-  const int i = (j0 + 2 * (int)blockIdx.x) * s;
-  const bool has_u = i - s >= 0, has_d = i + s < np;
+  const bool has_u = iu >= 0, has_d = id >= 0;
   const int k0 = i * NB;
   const int nb = (n - k0) < NB ? (n - k0) : NB;
   // thread (col, rq) sums rows rq, rq + 4, ... of its column: all three tiles are fetched up front
@@ -1037,8 +1036,8 @@ __global__ __launch_bounds__(256) void k_bcr_back(int n, int np, int s, int j0, 
     xi[q] = col <= r ? Dk[(int64_t)i * NB * NB + r * NB + col] : 0.0;  // lower triangle holds inv(L_i)
   }
   if (t < NB) {
-    xu[t] = has_u ? ek[(i - s) * NB + t] : 0.0;
-    xd[t] = has_d ? ek[(i + s) * NB + t] : 0.0;
+    xu[t] = has_u ? ek[iu * NB + t] : 0.0;
+    xd[t] = has_d ? ek[id * NB + t] : 0.0;
   }
   __syncthreads();
   double sacc = 0.0;
@@ -1057,6 +1056,126 @@ __global__ __launch_bounds__(256) void k_bcr_back(int n, int np, int s, int j0, 
     const double xk = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
     ek[k0 + t] = xk;
     if (t < nb) x_out[k0 + t] = xk;
+  }
+}
+
+// the blocks eliminated at stride s: one workgroup each
+__global__ __launch_bounds__(256) void k_bcr_back(int n, int np, int s, int j0, const double* __restrict__ Dk,
+                                                  const double* __restrict__ Pu, const double* __restrict__ Pd,
+                                                  double* __restrict__ ek, double* __restrict__ x_out) {
+  __shared__ double xu[NB], xd[NB], zv[NB];
+  __shared__ double part[4][NB];
+  const int i = (j0 + 2 * (int)blockIdx.x) * s;
+  bcr_back_block(n, i, i - s >= 0 ? i - s : -1, i + s < np ? i + s : -1, Dk, Pu, Pd, ek, x_out, xu, xd, zv, part);
+}
+
+// The last rounds of the reduction as one launch: when two or three blocks 0, s, 2s are left, one
+// workgroup walks them as a chain (factor, couple, update the next block, factor, ...; then the
+// substitutions backwards).  A round of the reduction costs an elimination, an update and later a
+// back-substitution launch for a single block each; the chain has the same factorisations on its
+// critical path and none of the launches between them.
+__global__ __launch_bounds__(256) void k_bcr_chain(int n, int np, int s, int cnt, double* __restrict__ Dk,
+                                                   const double* __restrict__ Bk, double* __restrict__ Pd,
+                                                   double* __restrict__ ek, double* __restrict__ x_out,
+                                                   int32_t* __restrict__ info) {
+  constexpr int NS = NB / SB;
+  __shared__ double L[NB * LDT];
+  __shared__ double X[NB * LDT];
+  __shared__ double Bt[NB * LDT];  // coupling S(next block, this block)
+  __shared__ double Pt[NB * LDT];  // the same times inv(L)^T
+  __shared__ double ev[NB], yv[NB], xu[NB], xd[NB], zv[NB];
+  __shared__ double part[4][NB];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  for (int idx = t; idx < NB * LDT; idx += 256) X[idx] = 0.0;
+  for (int c = 0; c < cnt; ++c) {
+    const int i = c * s;
+    const int k0 = i * NB;
+    const int nb = (n - k0) < NB ? (n - k0) : NB;
+    const bool has_next = c + 1 < cnt;
+    double* Di = Dk + (int64_t)i * NB * NB;
+    __syncthreads();  // the previous block's readers of L are done
+    tile_to_lds(Di, L, t);
+    if (t < NB) ev[t] = ek[k0 + t];
+    __syncthreads();
+    if (c > 0) {
+      // D_i -= P P^T (lower tiles (q, wave), wave <= q) and e_i -= P y of the block before
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+        if (wave <= q) {
+          d4_t c4;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) c4[g] = L[(q * SB + lk + 4 * g) * LDT + wave * SB + li];
+          tile_mma(Pt, false, q, Pt, wave, NS, true, li, lk, c4);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) L[(q * SB + lk + 4 * g) * LDT + wave * SB + li] = c4[g];
+        }
+      {
+        const int r = t & 63, q = t >> 6;
+        double sacc = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) sacc += Pt[r * LDT + 16 * q + cc] * yv[16 * q + cc];
+        part[q][r] = sacc;
+      }
+      __syncthreads();
+      if (t < NB) ev[t] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+    }
+    // the coupling to the next block arrives while the first block columns are factored
+    auto fetch = [&](int kk, int tt) {
+      if (kk != 0 || !has_next) return;
+      const double* g = Bk + (int64_t)i * NB * NB;
+      double v[NB * NB / 128];
+#pragma unroll
+      for (int it = 0; it < NB * NB / 128; ++it) v[it] = g[tt + 128 * it];
+#pragma unroll
+      for (int it = 0; it < NB * NB / 128; ++it) {
+        const int idx = tt + 128 * it;
+        Bt[(idx / NB) * LDT + idx % NB] = v[it];
+      }
+    };
+    diag_core(L, X, nullptr, n, k0, nb, Di, info, fetch);
+    // y_i = inv(L_i) e_i
+    {
+      const int r = t & 63, q = t >> 6;
+      double sacc = 0.0;
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) sacc += X[r * LDT + 16 * q + cc] * ev[16 * q + cc];
+      part[q][r] = sacc;
+    }
+    __syncthreads();
+    if (t < NB) {
+      const double y = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+      yv[t] = y;
+      ek[k0 + t] = y;
+    }
+    if (has_next) {
+      // P = S(next, i) inv(L_i)^T: wave w owns the blocks (I, (w - I) mod 4)
+      d4_t c4[NS];
+#pragma unroll
+      for (int I = 0; I < NS; ++I) {
+        const int J = (wave - I) & 3;
+        c4[I] = d4_t{0.0, 0.0, 0.0, 0.0};
+        tile_mma(Bt, false, I, X, J, J + 1, false, li, lk, c4[I]);
+      }
+      double* Pout = Pd + (int64_t)i * NB * NB;
+#pragma unroll
+      for (int I = 0; I < NS; ++I) {
+        const int J = (wave - I) & 3;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          Pt[(I * SB + lk + 4 * g) * LDT + J * SB + li] = c4[I][g];
+          Pout[(I * SB + lk + 4 * g) * NB + J * SB + li] = c4[I][g];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // backwards: x_i = inv(L_i)^T (y_i - P_i^T x_next); P_i sits where an eliminated block keeps its P_d
+  for (int c = cnt - 1; c >= 0; --c) {
+    bcr_back_block(n, c * s, -1, c + 1 < cnt ? (c + 1) * s : -1, Dk, Pd, Pd, ek, x_out, xu, xd, zv, part);
+    __syncthreads();
   }
 }
 
@@ -1176,14 +1295,13 @@ int launch_solve_band_packed(double* packed, int n, double mu_diag, double* da, 
   double* Pd = Pu + (int64_t)np * NB * NB;
   if (mu_diag != 0.0) hipLaunchKernelGGL(k_bcr_add_diagonal, dim3((n + 255) / 256), dim3(256), 0, st, Dk, n, mu_diag);
   int s = 1;
-  for (; s < np; s *= 2) {
+  for (; (np + s - 1) / s > 3; s *= 2) {
     const int m = (np + s - 1) / s;  // active blocks 0, s, 2s, ...
     hipLaunchKernelGGL(k_bcr_eliminate, dim3(m / 2), dim3(256), 0, st, n, np, s, 1, Dk, Bk, Pu, Pd, ek, info);
     hipLaunchKernelGGL(k_bcr_update, dim3(8 * ((m + 1) / 2)), dim3(256), 0, st, n, np, s, Dk, Bk, Pu, Pd, ek);
   }
-  // block 0 is what is left: no neighbours at this stride
-  hipLaunchKernelGGL(k_bcr_eliminate, dim3(1), dim3(256), 0, st, n, np, s, 0, Dk, Bk, Pu, Pd, ek, info);
-  hipLaunchKernelGGL(k_bcr_back, dim3(1), dim3(256), 0, st, n, np, s, 0, Dk, Pu, Pd, ek, da);
+  // at most three blocks are left: one workgroup walks them as a chain, substitutions included
+  hipLaunchKernelGGL(k_bcr_chain, dim3(1), dim3(256), 0, st, n, np, s, (np + s - 1) / s, Dk, Bk, Pd, ek, da, info);
   for (s /= 2; s >= 1; s /= 2) {
     const int m = (np + s - 1) / s;
     hipLaunchKernelGGL(k_bcr_back, dim3(m / 2), dim3(256), 0, st, n, np, s, 1, Dk, Pu, Pd, ek, da);
