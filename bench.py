@@ -251,7 +251,8 @@ def launch_ranks(n_ranks):
 
 
 def stage_times(prob, steps, warmup, world, barrier):
-    """(wall seconds for `steps` iterations with the stage kernels timed, per-kernel (ms total, launches))."""
+    """(wall seconds for `steps` iterations, per-kernel (ms total, launches) of the stage kernels, cost
+    after the last of those iterations)."""
     from sfm_amd import _lib
 
     for _ in range(warmup):
@@ -261,17 +262,28 @@ def stage_times(prob, steps, warmup, world, barrier):
     _lib.profile_read()
     # HIP events on the launch stream around the kernels of the three HBM stages and around the
     # reduced solve (what the roofline object is computed from).  A single rank enqueues nothing
-    # between the library's launches, so consecutive timed launches share an event.
+    # between the library's launches, so consecutive timed launches share an event and the records
+    # cost ~0.02 ms per iteration: they stay inside the timed region.  With several ranks the
+    # collectives sit between the launches, every launch needs two records of its own (~0.09 ms per
+    # iteration, which would be charged to the scaling curve): the timed region then runs without
+    # records and the kernels are timed in a pass of their own behind it.
     timed = sorted({k for names in GROUPS.values() for k in names} | {"solve_reduced"})
-    _lib.profile_enable(True, chained=(world == 1), kernels=timed)
+    if world == 1:
+        _lib.profile_enable(True, chained=True, kernels=timed)
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         prob.iterate_async()
     barrier()
     dt = time.perf_counter() - t0
+    final_cost = float(prob.cost_buf.item())  # after warm-up + K iterations, whatever the world size
+    if world > 1:
+        _lib.profile_enable(True, chained=False, kernels=timed)
+        for _ in range(steps):
+            prob.iterate_async()
+        barrier()
     _lib.profile_enable(False)
-    return dt, _lib.profile_read()
+    return dt, _lib.profile_read(), final_cost
 
 
 def stage_groups(prof, steps, N, n, m, s_blocks, pmc):
@@ -418,8 +430,7 @@ def main():
         torch.cuda.synchronize()
 
     # timed region: K iterations after W warm-up iterations
-    dt, prof = stage_times(prob, args.steps, args.warmup, world, barrier)
-    final_cost = float(prob.cost_buf.item())
+    dt, prof, final_cost = stage_times(prob, args.steps, args.warmup, world, barrier)
     prob.check_flags()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -509,7 +520,7 @@ def main():
             up = DeviceProblem(u.K, u.R, u.T, u.X, u.cam_idx, u.pt_idx, u.x_true, n_cams=m, check=True,
                                plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"))
             usteps = max(2, min(args.steps, 5))
-            udt, uprof = stage_times(up, usteps, 2, 1, barrier)
+            udt, uprof, _ = stage_times(up, usteps, 2, 1, barrier)
             up.check_flags()
             ub = 2 * up.plan.n_blocks - m
             out["uniform_visibility"] = {
