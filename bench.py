@@ -50,9 +50,9 @@ def algorithmic_bytes(N, n, m, s_blocks, with_B=False):
 # kernels only run when a caller asks for U / eps_a)
 GROUPS = {
     "jacobian": ["k_jacobian"],
-    "assembly": ["k_fused_runs", "k_fused_reduce", "k_fused_finish", "k_point", "k_camera_items", "k_camera_finish",
-                 "k_pair_blocks", "k_pair_finish"],
-    "back_substitution": ["k_back_substitute"],
+    "assembly": ["k_fused_state", "k_fused_runs", "k_fused_reduce", "k_fused_finish", "k_point", "k_camera_items",
+                 "k_camera_finish", "k_pair_blocks", "k_pair_finish"],
+    "back_substitution": ["k_back_substitute", "k_back_substitute_state"],
 }
 
 

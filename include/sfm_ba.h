@@ -181,6 +181,28 @@ int sfm_ba_schur_assemble(const sfm_ba_plan* plan, const double* d_A, const doub
                           void* d_workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Jacobian blocks and Schur assembly in one pass, for plans with runs (sfm_ba_plan_state_path
+ * returns 1): the rows of A and the residuals - compute_A_B and the projection of get_indices
+ * (src/bundle_adjustment.py:22-67, src/jacobian.py:21-220, src/utils.py:8-11) - are formed inside
+ * the assembly kernel from the prepared camera records (sfm_ba_camera_prepare), the projection
+ * matrices d_P [m,12], the points d_X [n,3] and d_x_true [N,2], and consumed there by calc_V_inv ...
+ * calc_e (src/sparse_ba.py:147-271): A, B and x_pred are never written to memory.  Outputs as
+ * sfm_ba_schur_assemble writes them without by-products (d_S lower triangle and row 7m, d_e, d_V_inv,
+ * d_eps_b); mu > 0.  The rows agree with those sfm_ba_jacobian writes to a few units in the last
+ * place (one reciprocal per quotient rule instead of a division per entry).
+ * ---------------------------------------------------------------------------------------- */
+int sfm_ba_plan_state_path(const sfm_ba_plan* plan);
+int sfm_ba_schur_assemble_state(const sfm_ba_plan* plan, const double* d_cam_blk, const double* d_P, const double* d_X,
+                                const double* d_x_true, double mu, double mu_u, double* d_S, double* d_e,
+                                double* d_V_inv, double* d_eps_b, void* d_workspace, void* stream);
+/* calc_delta_b (src/sparse_ba.py:279-290) the same way: the rows of A are formed again from the camera
+ * records and d_X (the state the system was assembled at: call it before the cameras are updated).
+ * update_points != 0: d_X += x_step * delta_b afterwards (src/bundle_adjustment.py:100), point by point. */
+int sfm_ba_back_substitute_state(const sfm_ba_plan* plan, const double* d_cam_blk, const double* d_V_inv,
+                                 const double* d_eps_b, const double* d_delta_a, double* d_delta_b, double* d_X,
+                                 int update_points, double x_step, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * The same three stages on "step blocks", for plans with runs (sfm_ba_plan_fused_info): the layout
  * the loop uses when nobody needs A in the reference's [N,2,7] form.  A step is up to 8 consecutive
  * points of one run; its block holds, for every (point, camera slot of the run's window), the row

@@ -23,6 +23,7 @@ constexpr int kPairPartStride = 56;  // doubles per partial result of a split bl
 // of a wave then owns one observation or none, 8 points per step.
 constexpr int kFzLanesPerPoint = 8;  // lanes (= slot positions of the table) per point
 constexpr int kFzMaxPmax = 1024;     // longest range of points one wave walks (and with it: runs per range)
+constexpr int kFzMaxRunsPerRange = 256;  // what the kernel that forms A itself keeps of a range's run boundaries
 constexpr int kFzSlotSums = 35;      // per-camera-slot sums behind a partial's tiles: 28 (upper triangle of
                                      // sum A^T A) + 7 (sum A^T g); 7 more per extra row
 struct FzShape {
@@ -105,6 +106,7 @@ struct sfm_ba_plan {
   // fused point-major assembly (fz_slots = 0: the visibility pattern does not allow it)
   int32_t fz_slots = 0, fz_group = 0, fz_pmax = 0, fz_enabled = 1;
   int32_t n_runs = 0, n_keys = 0, n_ranges = 0, n_steps = 0;
+  int32_t fz_max_range_runs = 0;  // most runs inside one range of fz_pmax points
   int32_t* d_run_pt0 = nullptr;   // [n_runs+1] first point of each run
   int32_t* d_run_base = nullptr;  // [n_runs] first camera of the run's window
   int32_t* d_rng_run = nullptr;   // [n_ranges+1] first run of every range of fz_pmax points (one wave per range)
@@ -130,7 +132,7 @@ void plan_set_workspace(sfm_ba_plan* p);  // workspace section offsets from the 
 enum KernelId {
   KID_CAMERA_PREPARE = 0, KID_JACOBIAN, KID_POINT, KID_CAMERA_ITEMS, KID_CAMERA_FINISH, KID_PAIR_BLOCKS,
   KID_PAIR_FINISH, KID_SOLVE, KID_BACK, KID_UPDATE, KID_COST_ITEMS, KID_COST_FINISH, KID_CALC_W_Y, KID_TRIANGULATE, KID_FUSED_RUNS,
-  KID_FUSED_REDUCE, KID_FUSED_FINISH, KID_COUNT
+  KID_FUSED_REDUCE, KID_FUSED_FINISH, KID_FUSED_STATE, KID_BACK_STATE, KID_COUNT
 };
 bool profiling_enabled();
 class ProfScope {
@@ -177,6 +179,12 @@ int launch_back_substitute_steps(const sfm_ba_plan* p, const double* steps, cons
 int launch_calc_W_Y(const sfm_ba_plan* p, const double* A, const double* B, const double* w,
                     const double* Vinv, const int32_t* pt, double* W, double* Y, hipStream_t st);
 int launch_add_diagonal(double* S, int n7, double mu, hipStream_t st);
+bool fz_state_applies(const sfm_ba_plan* p);
+int launch_assemble_state(const sfm_ba_plan* p, const double* blk, const double* P, const double* X, const double* xt,
+                          double mu, double mu_u, double* S, double* e, double* Vinv, double* eps_b, void* ws,
+                          hipStream_t st);
+int launch_back_substitute_state(const sfm_ba_plan* p, const double* blk, const double* Vinv, const double* eps_b,
+                                 const double* da, double* db, double* X, int update, double x_step, hipStream_t st);
 int launch_status(const double* cost, const int32_t* info, const int32_t* fa, const int32_t* fb, int m, double* out,
                   hipStream_t st);
 int launch_lower_pack(const double* S, int n7, double* tri, hipStream_t st);

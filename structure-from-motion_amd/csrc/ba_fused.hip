@@ -134,6 +134,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
   constexpr int64_t STRIDE = fz_part_stride_c(T, E);
   __shared__ __attribute__((aligned(16))) double Zp[24 * KS];  // [K column = 3 point + q][8 slot + r]
   __shared__ int bnd[kFzMaxPmax + 1];  // first point of every run of this wave's range, and the range's end
+#define FZ_RESIDUAL_IN_ROWS BLOCKED
   const int lane = threadIdx.x;
   const double* zero_row = g_fz_zero_row;
   const int p = lane >> 3, s = lane & 7;
@@ -237,119 +238,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
     FZ_STAMP_WAIT("vmcnt(0)");
     FZ_STAMP(1);  // operands of this step
 
-    // ---- per observation: point block and residual.  The point block B is minus the camera-centre
-    // columns of A; the arithmetic below works with b = -B (those columns as they are): V = b^T b,
-    // q = b^T eps = -eps_b, g = eps + b V^-1 q, and Z comes out with the opposite sign, which Z Z^T
-    // does not see ----
-    const double b0 = a_(4), b1 = a_(5), b2 = a_(6), b3 = a_(11), b4 = a_(12), b5 = a_(13);
-    const double e0 = BLOCKED ? a_(14) : a_(14) - a_(16), e1 = BLOCKED ? a_(15) : a_(15) - a_(17);
-    // B^T B (00 01 02 11 12 22) and B^T eps, summed over the observations of the point
-    const double v00 = sum8(b0 * b0 + b3 * b3) + mu;
-    const double v01 = sum8(b0 * b1 + b3 * b4);
-    const double v02 = sum8(b0 * b2 + b3 * b5);
-    const double v11 = sum8(b1 * b1 + b4 * b4) + mu;
-    const double v12 = sum8(b1 * b2 + b4 * b5);
-    const double v22 = sum8(b2 * b2 + b5 * b5) + mu;
-    const double q0 = sum8(b0 * e0 + b3 * e1);
-    const double q1 = sum8(b1 * e0 + b4 * e1);
-    const double q2 = sum8(b2 * e0 + b5 * e1);
-    // V = C C^T (V is symmetric positive definite for mu > 0), G = C^-1 (lower triangular):
-    // V^-1 = G^T G, and Z = W G^T satisfies Z Z^T = W V^-1 W^T.  No division: the reciprocal
-    // square roots of the pivots are all that is needed.
-    const double rp0 = rsqrt_nr(v00);
-    const double c10 = v01 * rp0, c20 = v02 * rp0;
-    const double d1 = fma(-c10, c10, v11);
-    const double rp1 = rsqrt_nr(d1);
-    const double c21 = fma(-c20, c10, v12) * rp1;
-    const double d2 = fma(-c21, c21, fma(-c20, c20, v22));
-    const double rp2 = rsqrt_nr(d2);
-    const double g10 = -c10 * rp0 * rp1;
-    const double g21 = -c21 * rp1 * rp2;
-    const double g20 = -(c20 * rp0 + c21 * g10) * rp2;
-    const double i00 = fma(g20, g20, fma(g10, g10, rp0 * rp0));
-    const double i01 = fma(g20, g21, g10 * rp1);
-    const double i02 = g20 * rp2;
-    const double i11 = fma(g21, g21, rp1 * rp1);
-    const double i12 = g21 * rp2;
-    const double i22 = rp2 * rp2;
-    if (pt < pt1) {
-      // lane s < 3 of the point stores row s of V^-1 and entry s of eps_b.  Three masked blocks on
-      // laundered copies of s: a selection by s (of values or of addresses) is turned into a table
-      // in scratch memory by the compiler
-      double* vo = Vinv + 9 * (int64_t)pt;
-      double* eo = eps_b + 3 * (int64_t)pt;
-      int sa = s, sb = s, sc = s;
-      asm volatile("" : "+v"(sa));
-      asm volatile("" : "+v"(sb));
-      asm volatile("" : "+v"(sc));
-      if (sa == 0) { vo[0] = i00; vo[1] = i01; vo[2] = i02; eo[0] = -q0; }
-      if (sb == 1) { vo[3] = i01; vo[4] = i11; vo[5] = i12; eo[1] = -q1; }
-      if (sc == 2) { vo[6] = i02; vo[7] = i12; vo[8] = i22; eo[2] = -q2; }
-    }
-    const double z0 = i00 * q0 + i01 * q1 + i02 * q2;
-    const double z1 = i01 * q0 + i11 * q1 + i12 * q2;
-    const double z2 = i02 * q0 + i12 * q1 + i22 * q2;
-    const double g0 = e0 - (b0 * z0 + b1 * z1 + b2 * z2);  // (-B)(-V^-1 eps_b) = B V^-1 eps_b
-    const double g1 = e1 - (b3 * z0 + b4 * z1 + b5 * z2);
-    // ---- B G^T (2 x 3): column q is sum_{a <= q} B[:, a] G[q][a]; then Z = A^T (B G^T) ----
-    const double m00 = b0 * rp0, m01 = fma(b1, rp1, b0 * g10), m02 = fma(b2, rp2, fma(b1, g21, b0 * g20));
-    const double m10 = b3 * rp0, m11 = fma(b4, rp1, b3 * g10), m12 = fma(b5, rp2, fma(b4, g21, b3 * g20));
-    __builtin_amdgcn_sched_barrier(0);  // (phases kept apart: interleaving them costs registers)
-    // ---- per camera slot: U_j += A^T A, e_j += A^T g ----
-    {
-      int v = 0;
-#pragma unroll
-      for (int r = 0; r < 7; ++r) {
-#pragma unroll
-        for (int c = r; c < 7; ++c, ++v) u[v] = fma(a_(7 + r), a_(7 + c), fma(a_(r), a_(c), u[v]));
-        ev[r] = fma(a_(7 + r), g1, fma(a_(r), g0, ev[r]));
-      }
-    }
-    // ---- rows behind the tiles: D[x][7 s + r] += sum_q Z_x[q] Z_s[r][q] with Z_s[r][q] = A_s[:, r] . M_s[:, q]
-    // is A_s[:, r] . h, h = M_s Z_x^T: the same shape as e_j.  Z_x (row x of the panel's slot sx) comes
-    // from lane sx of the point by DPP ----
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      constexpr int dummy = 16 * T;
-      const int rho = dummy + e;
-      const int rx = rho % 7;
-      const double w0 = fma(a_(7 + rx), m10, a_(rx) * m00);
-      const double w1 = fma(a_(7 + rx), m11, a_(rx) * m01);
-      const double w2 = fma(a_(7 + rx), m12, a_(rx) * m02);
-      double x0, x1, x2;
-      if ((dummy + e) / 7 == 4) {
-        x0 = bcast8<4>(w0, s); x1 = bcast8<4>(w1, s); x2 = bcast8<4>(w2, s);
-      } else {
-        x0 = bcast8<6>(w0, s); x1 = bcast8<6>(w1, s); x2 = bcast8<6>(w2, s);
-      }
-      const double h0 = fma(x2, m02, fma(x1, m01, x0 * m00));
-      const double h1 = fma(x2, m12, fma(x1, m11, x0 * m10));
-#pragma unroll
-      for (int r = 0; r < 7; ++r) xa[e][r] = fma(a_(7 + r), h1, fma(a_(r), h0, xa[e][r]));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    FZ_STAMP(2);  // per-point phase, U, e, rows behind the tiles
-    // ---- Z into the panel (slots at and beyond W never hold an observation: their lanes write the
-    // zeros that the operand reads of rows past the window pick up at offset 7) ----
-    {
-      double* zp = Zp + (3 * p) * KS + 8 * s;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const double ma = q == 0 ? m00 : (q == 1 ? m01 : m02);
-        const double mb = q == 0 ? m10 : (q == 1 ? m11 : m12);
-        double z[7];
-#pragma unroll
-        for (int r = 0; r < 7; ++r) z[r] = fma(a_(7 + r), mb, a_(r) * ma);
-        sts2(zp + q * KS, z[0], z[1]);
-        sts2(zp + q * KS + 2, z[2], z[3]);
-        sts2(zp + q * KS + 4, z[4], z[5]);
-        sts2(zp + q * KS + 6, z[6], 0.0);
-      }
-    }
-    // one wave wrote the panel and reads it: its LDS operations complete in order
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#include "ba_fused_step_a.inc"
     // ---- next step's operands on their way while the matrix cores work ----
     FZ_STAMP(3);  // Z and its stores
     FZ_STAMP_WAIT("lgkmcnt(0)");
@@ -368,81 +257,10 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
     if (r2 < nr) FZ_ADVANCE(f2, r2);
     pos_next2 = !BLOCKED && r2 < nr ? FZ_FETCH_POS(f2, FZ_LIM(r2)) : -1;
     FZ_STAMP(5);  // fetches of the next step issued
-#pragma unroll
-    for (int kk = 0; kk < 6; ++kk) {
-      double zt[T];
-#pragma unroll
-      for (int t = 0; t < T; ++t) zt[t] = Zp[(4 * kk + lk) * KS + roff[t]];
-      int idx = 0;
-#pragma unroll
-      for (int ti = 0; ti < T; ++ti)
-#pragma unroll
-        for (int tj = 0; tj <= ti; ++tj, ++idx)
-          acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(zt[ti], zt[tj], acc[idx], 0, 0, 0);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+#include "ba_fused_step_b.inc"
     FZ_STAMP(6);  // matrix phase issued
   } while (++step < nsteps);
-    {
-      // ---- the run's partial result: tiles as they lie in the registers, the extra rows, the per-slot
-      // sums; then everything starts from zero for the next run ----
-      // (every index below is rebuilt from a laundered copy of the lane id: values that stay live
-      // across the steps for the sake of this block end up in scratch memory, and a reload from there
-      // is followed by a wait for everything in flight - the stores issued just before included)
-      int fl = lane;
-      asm volatile("" : "+v"(fl));
-      const int fli = fl & 15, flk = fl >> 4;
-      double* po = part + (int64_t)run * STRIDE;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) po[t * 256 + (flk + 4 * v) * 16 + fli] = acc[t][v];
-        acc[t] = d4_t{0.0, 0.0, 0.0, 0.0};
-      }
-      FZ_STAMP(8);  // tiles of the run stored
-      // the per-slot sums (28 + 7 + 7 E values per lane) are added over the 8 points through the
-      // panel's LDS, 21 values at a time: lane l parks value j at [j][l], then lane (j, slot) adds the
-      // eight entries [j][8 p + slot] in the order of p and stores the sum
-      constexpr int NV = kFzSlotSums + 7 * E;
-#pragma unroll
-      for (int c0 = 0; c0 < NV; c0 += 21) {
-        const int cnt = NV - c0 < 21 ? NV - c0 : 21;
-#pragma unroll
-        for (int j = 0; j < 21; ++j) {
-          const int i = c0 + j;
-          if (i < NV) Zp[j * 64 + fl] = i < 28 ? u[i < 28 ? i : 0] : (i < 35 ? ev[i < 35 && i >= 28 ? i - 28 : 0] : xa[i >= 35 ? (i - 35) / 7 : 0][i >= 35 ? (i - 35) % 7 : 0]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        FZ_STAMP(9);  // sums parked in LDS
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const int o = 64 * k + fl;
-          if (o < 8 * cnt) {
-            const int j = o >> 3, ss = o & 7;
-            const double* z = Zp + j * 64 + ss;
-            double sum = z[0];
-#pragma unroll
-            for (int pp = 1; pp < 8; ++pp) sum += z[8 * pp];
-            po[NT * 256 + 8 * c0 + o] = sum;  // value i of slot ss at [i][ss]: whole lines per store
-          }
-        }
-        FZ_STAMP(10);  // sums added and their stores issued
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-#pragma unroll
-      for (int i = 0; i < 28; ++i) u[i] = 0.0;
-#pragma unroll
-      for (int i = 0; i < 7; ++i) ev[i] = 0.0;
-#pragma unroll
-      for (int e = 0; e < E; ++e)
-#pragma unroll
-        for (int i = 0; i < 7; ++i) xa[e][i] = 0.0;
-      FZ_STAMP(7);  // partial result of a run
-    }
+#include "ba_fused_flush.inc"
   }
   FZ_STAMP_FLUSH;
 #undef FZ_FETCH_POS
@@ -450,6 +268,363 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
 #undef FZ_ADVANCE
 #undef FZ_LIM
 #undef a_
+#undef FZ_RESIDUAL_IN_ROWS
+}
+
+// ---- the same assembly straight from the state -------------------------------------------------
+// 1 / x to full precision: hardware estimate and two Newton steps (x is a depth or its square: never 0)
+__device__ __forceinline__ double fz_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+}
+
+// Row of A and residual of one observation, formed where they are used instead of being read back
+// from memory: the arithmetic of jacobian_rows (src/jacobian.py:21-220) and of the projection
+// (src/utils.py:8-11) on the camera's prepared record `rec` (56 doubles) and projection matrix `pm`
+// (12) in LDS, with one reciprocal per quotient rule instead of fourteen divisions (a few units in
+// the last place from the rows k_jacobian writes).  av[0..6] = row of A as k_jacobian lays it out,
+// av[7] = x_true - x_pred; zeros for a lane without an observation.
+template <bool RESIDUAL = true, bool FENCED = false>
+__device__ __forceinline__ void fz_rows_from_state(const double* __restrict__ rec, const double* __restrict__ pm,
+                                                   double x0, double x1, double x2, double2 xt, bool has,
+                                                   double2 (&av)[9]) {
+  // (FENCED: in four parts fenced off from each other.  Left alone, the scheduler moves all 34 LDS reads
+  // to the front: 68 registers, which a kernel compiled for two waves per SIMD does not have to spare;
+  // a kernel with one wave per SIMD wants exactly that, nothing else hides the latency of the reads)
+  const double2* r2 = reinterpret_cast<const double2*>(rec);
+  const double z = 0.0;
+  double d0, d1, d2, wi, ui, vi;
+  {
+    const double2 c01 = r2[0], c23 = r2[1], c45 = r2[2], c67 = r2[3], c89 = r2[4], cab = r2[5];
+    const double mu0 = c01.x, mu1 = c01.y, mu2 = c23.x, mv0 = c23.y, mv1 = c45.x, mv2 = c45.y;
+    const double mw0 = c67.x, mw1 = c67.y, mw2 = c89.x;
+    d0 = x0 - c89.y;
+    d1 = x1 - cab.x;
+    d2 = x2 - cab.y;
+    const double u = mu0 * d0 + mu1 * d1 + mu2 * d2;
+    const double v = mv0 * d0 + mv1 * d1 + mv2 * d2;
+    const double w = mw0 * d0 + mw1 * d1 + mw2 * d2;
+    const double iw2 = fz_rcp(w * w);
+    // a lane without an observation: zero scale factors make every entry below an exact zero (the
+    // other factors are finite: its record and point are those of existing cameras and points)
+    wi = has ? w * iw2 : z;
+    ui = has ? u * iw2 : z;
+    vi = has ? v * iw2 : z;
+    // dF/dX rows (the point block); dF/dC = -dF/dX sits in columns 4..6 of A
+    const double b00 = fma(wi, mu0, -ui * mw0), b01 = fma(wi, mu1, -ui * mw1), b02 = fma(wi, mu2, -ui * mw2);
+    const double b10 = fma(wi, mv0, -vi * mw0), b11 = fma(wi, mv1, -vi * mw1), b12 = fma(wi, mv2, -vi * mw2);
+    av[2] = make_double2(-b00, -b01);
+    av[3].x = -b02;
+    av[5].y = -b10;
+    av[6] = make_double2(-b11, -b12);
+  }
+  if (FENCED) __builtin_amdgcn_sched_barrier(0);
+  const double2 f01 = r2[26], f23 = r2[27];  // fx fy | ox oy
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    // columns 2 h, 2 h + 1 of the 9 x 4 table dR/dQ: row 3 r + i at doubles 12 + 4 (3 r + i)
+    double g[3][2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double2 t0 = r2[6 + 2 * (3 * r + 0) + h], t1 = r2[6 + 2 * (3 * r + 1) + h], t2 = r2[6 + 2 * (3 * r + 2) + h];
+      g[r][0] = d0 * t0.x + d1 * t1.x + d2 * t2.x;
+      g[r][1] = d0 * t0.y + d1 * t1.y + d2 * t2.y;
+    }
+    double a0[2], a1[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const double du = f01.x * g[0][c] + f23.x * g[2][c];
+      const double dv = f01.y * g[1][c] + f23.y * g[2][c];
+      a0[c] = fma(wi, du, -ui * g[2][c]);
+      a1[c] = fma(wi, dv, -vi * g[2][c]);
+    }
+    if (h == 0) {
+      av[0] = make_double2(a0[0], a0[1]);
+      av[3].y = a1[0];
+      av[4].x = a1[1];
+    } else {
+      av[1] = make_double2(a0[0], a0[1]);
+      av[4].y = a1[0];
+      av[5].x = a1[1];
+    }
+    if (FENCED) __builtin_amdgcn_sched_barrier(0);
+  }
+  if (RESIDUAL) {
+    const double2* p2 = reinterpret_cast<const double2*>(pm);
+    const double2 p01 = p2[0], p23 = p2[1], p45 = p2[2], p67 = p2[3], p89 = p2[4], pab = p2[5];
+    const double h0 = p01.x * x0 + p01.y * x1 + p23.x * x2 + p23.y;
+    const double h1 = p45.x * x0 + p45.y * x1 + p67.x * x2 + p67.y;
+    const double h2 = p89.x * x0 + p89.y * x1 + pab.x * x2 + pab.y;
+    const double ih2 = fz_rcp(h2);
+    av[7] = make_double2(has ? xt.x - h0 * ih2 : z, has ? xt.y - h1 * ih2 : z);
+  }
+}
+
+// k_fused_runs with the rows of A and the residuals formed in the kernel from the camera records,
+// the points and x_true: A, B and x_pred never exist in memory.  The records and projection
+// matrices of the 8 cameras of the current run's window sit in LDS (4 352 bytes, reloaded when the
+// next step belongs to another run); the point and x_true of the next step are fetched at the top of
+// a step and turned into its operands behind the panel stores, where k_fused_runs issues its gathers.
+template <int W, int T, int E, int WPS>
+__global__ __launch_bounds__(64, WPS) void k_fused_state(
+    const int32_t* __restrict__ rng_run, const int32_t* __restrict__ run_pt0, const int32_t* __restrict__ run_base,
+    const int32_t* __restrict__ slot_obs, const double* __restrict__ blk, const double* __restrict__ P,
+    const double* __restrict__ X, const double* __restrict__ xt, double mu, double* __restrict__ Vinv,
+    double* __restrict__ eps_b, double* __restrict__ part, int pmax, int n_pts, int m) {
+  static_assert(16 * T + E >= 7 * W && 16 * T <= 7 * W + 15, "tiles and extra rows must cover the window");
+  constexpr int KS = 64;
+  constexpr int NT = T * (T + 1) / 2;
+  constexpr int64_t STRIDE = fz_part_stride_c(T, E);
+  constexpr int REC = SFM_BA_CAM_BLK;
+  constexpr int RS = REC + 2;  // record stride in LDS: 58 doubles = 116 dwords, the 8 cameras' 16-byte reads hit 8 different bank groups
+  __shared__ __attribute__((aligned(16))) double Zp[24 * KS];
+  __shared__ __attribute__((aligned(16))) double sRec[8 * (RS + 12)];  // 8 records, then 8 projection matrices
+  __shared__ int bnd[kFzMaxRunsPerRange + 1];
+#define FZ_RESIDUAL_IN_ROWS true
+  const int lane = threadIdx.x;
+  const int p = lane >> 3, s = lane & 7;
+  const int li = lane & 15, lk = lane >> 4;
+  int roff[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int rho = 16 * t + li;
+    roff[t] = rho < 7 * W ? 8 * (rho / 7) + rho % 7 : 7;
+  }
+  FZ_STAMP_DECL;
+  const int run0 = rng_run[blockIdx.x];
+  const int nr = rng_run[blockIdx.x + 1] - run0;
+  int f0 = blockIdx.x * pmax, r0 = 0;
+#define FZ_FETCH_POS(first, lim) \
+  (((first) + p) < (lim) ? slot_obs[(unsigned)(kFzLanesPerPoint * ((first) + p) + s)] : -1)
+#define FZ_ADVANCE(first, r)                                                    \
+  do {                                                                          \
+    (first) += 8;                                                               \
+    if ((first) >= __builtin_amdgcn_readfirstlane(bnd[(r) + 1])) {              \
+      (r) += 1;                                                                 \
+      (first) = __builtin_amdgcn_readfirstlane(bnd[(r)]);                       \
+    }                                                                           \
+  } while (0)
+#define FZ_LIM(r) __builtin_amdgcn_readfirstlane(bnd[(r) + 1])
+  // records and projection matrices of the window of run `rr` (relative to run0) into LDS; cameras
+  // past the last one read as the last (their slots hold no observation)
+#define FZ_LOAD_WINDOW(rr)                                                                         \
+  do {                                                                                             \
+    const int base_ = __builtin_amdgcn_readfirstlane(run_base[run0 + (rr)]);                       \
+    const double2* src_ = reinterpret_cast<const double2*>(blk);                                   \
+    double2* dst_ = reinterpret_cast<double2*>(sRec);                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < (8 * REC / 2 + 63) / 64; ++i_) {                       \
+      const int e_ = lane + 64 * i_;                                                               \
+      if (e_ < 8 * REC / 2) {                                                                      \
+        int c_ = base_ + e_ / (REC / 2);                                                           \
+        c_ = c_ < m ? c_ : m - 1;                                                                  \
+        dst_[(e_ / (REC / 2)) * (RS / 2) + e_ % (REC / 2)] = src_[(int64_t)c_ * (REC / 2) + e_ % (REC / 2)]; \
+      }                                                                                            \
+    }                                                                                              \
+    if (lane < 48) {                                                                               \
+      int c_ = base_ + lane / 6;                                                                   \
+      c_ = c_ < m ? c_ : m - 1;                                                                    \
+      dst_[8 * RS / 2 + lane] = reinterpret_cast<const double2*>(P)[(int64_t)c_ * 6 + lane % 6];   \
+    }                                                                                              \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                         \
+    __builtin_amdgcn_wave_barrier();                                                               \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                         \
+  } while (0)
+  // point and pixel of this lane's observation in the step that starts at `first` (lanes without one:
+  // the step's point all the same - it exists - and the first pixel)
+#define FZ_FETCH_STATE(first, pos_, X0, X1, X2, XT)                        \
+  do {                                                                     \
+    int pt_ = (first) + p;                                                 \
+    pt_ = pt_ < n_pts ? pt_ : n_pts - 1;                                   \
+    const double* xp_ = X + 3 * (int64_t)pt_;                              \
+    X0 = xp_[0];                                                           \
+    X1 = xp_[1];                                                           \
+    X2 = xp_[2];                                                           \
+    XT = ldg2(xt + 2 * (int64_t)((pos_) >= 0 ? (pos_) : 0));               \
+  } while (0)
+  const int pt_first = f0 + p < n_pts ? f0 + p : n_pts - 1;
+  const int pos_raw = slot_obs[(unsigned)(kFzLanesPerPoint * pt_first + s)];
+  for (int i = lane; i <= nr; i += 64) bnd[i] = run_pt0[run0 + i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  double2 av[9];
+#define a_(i) (((i) & 1) ? av[(i) >> 1].y : av[(i) >> 1].x)
+  int pos = f0 + p < FZ_LIM(0) ? pos_raw : -1;
+  int r_win = 0;  // run whose window sits in LDS
+  FZ_LOAD_WINDOW(0);
+  double xn0, xn1, xn2;
+  double2 xtn;
+  FZ_FETCH_STATE(f0, pos, xn0, xn1, xn2, xtn);
+  fz_rows_from_state<true, WPS == 2>(sRec + RS * s, sRec + 8 * RS + 12 * s, xn0, xn1, xn2, xtn, pos >= 0, av);
+  int f1 = f0, r1 = r0;
+  FZ_ADVANCE(f1, r1);
+  int pos_next = r1 < nr ? FZ_FETCH_POS(f1, FZ_LIM(r1)) : -1;
+  int f2 = f1, r2 = r1;
+  if (r2 < nr) FZ_ADVANCE(f2, r2);
+  int pos_next2 = r2 < nr ? FZ_FETCH_POS(f2, FZ_LIM(r2)) : -1;
+
+  d4_t acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = d4_t{0.0, 0.0, 0.0, 0.0};
+  double u[28], ev[7], xa[E > 0 ? E : 1][7];
+#pragma unroll
+  for (int i = 0; i < 28; ++i) u[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) ev[i] = 0.0;
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+#pragma unroll
+    for (int i = 0; i < 7; ++i) xa[e][i] = 0.0;
+
+  FZ_STAMP(0);
+  while (r0 < nr) {  // runs of the range
+  const int run = run0 + r0;
+  int nsteps = (FZ_LIM(r0) - f0 + 7) >> 3;
+  asm volatile("" : "+s"(nsteps));
+  int step = 0;
+  do {
+    const int pt = f0 + p;
+    const int pt1 = FZ_LIM(r0);
+    // the next step's point and pixel: on their way during this step's arithmetic
+    if (r1 < nr) FZ_FETCH_STATE(f1, pos_next, xn0, xn1, xn2, xtn);
+    FZ_STAMP(1);
+#include "ba_fused_step_a.inc"
+    FZ_STAMP(3);
+    FZ_STAMP_WAIT("lgkmcnt(0)");
+    FZ_STAMP(4);
+    f0 = f1; r0 = r1;
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    pos = pos_next;
+    if (r0 < nr) {
+      if (r0 != r_win) {
+        FZ_LOAD_WINDOW(r0);
+        r_win = r0;
+      }
+      fz_rows_from_state<true, WPS == 2>(sRec + RS * s, sRec + 8 * RS + 12 * s, xn0, xn1, xn2, xtn, pos >= 0, av);
+    }
+    f1 = f2; r1 = r2;
+    pos_next = pos_next2;
+    if (r2 < nr) FZ_ADVANCE(f2, r2);
+    pos_next2 = r2 < nr ? FZ_FETCH_POS(f2, FZ_LIM(r2)) : -1;
+    FZ_STAMP(5);
+#include "ba_fused_step_b.inc"
+    FZ_STAMP(6);
+  } while (++step < nsteps);
+#include "ba_fused_flush.inc"
+  }
+  FZ_STAMP_FLUSH;
+#undef FZ_FETCH_POS
+#undef FZ_FETCH_STATE
+#undef FZ_LOAD_WINDOW
+#undef FZ_ADVANCE
+#undef FZ_LIM
+#undef a_
+#undef FZ_RESIDUAL_IN_ROWS
+}
+
+// Back-substitution straight from the state (src/sparse_ba.py:279-290 and the point update of
+// src/bundle_adjustment.py:100): delta_b_i = V_i^-1 (eps_b_i - sum_s B_s^T A_s delta_a[cam_s]) with the
+// rows of A formed in the kernel as in k_fused_state (B = minus the camera-centre columns of A).
+// One wave per range of points, a step of 8 points at a time; the window's camera records and its 56
+// entries of delta_a sit in LDS.  X is read before it is updated: a point's rows depend on no other point.
+__global__ __launch_bounds__(64) void k_back_substitute_state(
+    const int32_t* __restrict__ rng_run, const int32_t* __restrict__ run_pt0, const int32_t* __restrict__ run_base,
+    const int32_t* __restrict__ slot_obs, const double* __restrict__ blk, const double* __restrict__ Vinv,
+    const double* __restrict__ eps_b, const double* __restrict__ da, double* __restrict__ db, double* __restrict__ X,
+    int update, double x_step, int pmax, int n_pts, int m) {
+  constexpr int REC = SFM_BA_CAM_BLK;
+  __shared__ __attribute__((aligned(16))) double sRec[8 * REC];
+  __shared__ double sDa[56];
+  const int lane = threadIdx.x;
+  const int p = lane >> 3, s = lane & 7;
+  const int run_first = rng_run[blockIdx.x], run_last = rng_run[blockIdx.x + 1];
+  for (int run = run_first; run < run_last; ++run) {
+    const int base = __builtin_amdgcn_readfirstlane(run_base[run]);
+    const int beg = __builtin_amdgcn_readfirstlane(run_pt0[run]), end = __builtin_amdgcn_readfirstlane(run_pt0[run + 1]);
+    {
+      const double2* src = reinterpret_cast<const double2*>(blk);
+      double2* dst = reinterpret_cast<double2*>(sRec);
+#pragma unroll
+      for (int i = 0; i < (8 * REC / 2 + 63) / 64; ++i) {
+        const int e = lane + 64 * i;
+        if (e < 8 * REC / 2) {
+          int c = base + e / (REC / 2);
+          c = c < m ? c : m - 1;
+          dst[e] = src[(int64_t)c * (REC / 2) + e % (REC / 2)];
+        }
+      }
+      if (lane < 56) {
+        int c = base + lane / 7;
+        c = c < m ? c : m - 1;
+        sDa[lane] = da[7 * (int64_t)c + lane % 7];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // the table entry and the point of a step are fetched one step ahead, V^-1 and eps_b of the step at
+    // its top: nothing below waits for a load it has just issued
+    int pos_n;
+    double xn0, xn1, xn2;
+#define FZ_BS_FETCH(first)                                                                \
+  do {                                                                                    \
+    const int ptn_ = (first) + p < end ? (first) + p : end - 1;                           \
+    pos_n = (first) + p < end ? slot_obs[(unsigned)(kFzLanesPerPoint * ptn_ + s)] : -1;   \
+    const double* xq_ = X + 3 * (int64_t)ptn_;                                            \
+    xn0 = xq_[0];                                                                         \
+    xn1 = xq_[1];                                                                         \
+    xn2 = xq_[2];                                                                         \
+  } while (0)
+    FZ_BS_FETCH(beg);
+    for (int f = beg; f < end; f += 8) {
+      const int pt = f + p;
+      const bool live = pt < end;
+      const int pos = pos_n;
+      const double x0 = xn0, x1 = xn1, x2 = xn2;
+      if (f + 8 < end) FZ_BS_FETCH(f + 8);
+      double vv[9], eb[3];
+      if (s == 0 && live) {
+        const double* v = Vinv + 9 * (int64_t)pt;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) vv[i] = v[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) eb[i] = eps_b[3 * (int64_t)pt + i];
+      }
+      double2 av[9];
+      fz_rows_from_state<false>(sRec + REC * s, nullptr, x0, x1, x2, make_double2(0.0, 0.0), pos >= 0, av);
+#define a_(i) (((i) & 1) ? av[(i) >> 1].y : av[(i) >> 1].x)
+      const double* dj = sDa + 7 * s;
+      double h0 = 0.0, h1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        h0 += a_(q) * dj[q];
+        h1 += a_(7 + q) * dj[q];
+      }
+      const double c0 = sum8(-a_(4) * h0 - a_(11) * h1);
+      const double c1 = sum8(-a_(5) * h0 - a_(12) * h1);
+      const double c2 = sum8(-a_(6) * h0 - a_(13) * h1);
+#undef a_
+      if (s == 0 && live) {
+        const double r0 = eb[0] - c0, r1 = eb[1] - c1, r2 = eb[2] - c2;
+        const double d0 = vv[0] * r0 + vv[1] * r1 + vv[2] * r2;
+        const double d1 = vv[3] * r0 + vv[4] * r1 + vv[5] * r2;
+        const double d2 = vv[6] * r0 + vv[7] * r1 + vv[8] * r2;
+        db[3 * (int64_t)pt] = d0; db[3 * (int64_t)pt + 1] = d1; db[3 * (int64_t)pt + 2] = d2;
+        if (update) {
+          X[3 * (int64_t)pt] = x0 + x_step * d0;
+          X[3 * (int64_t)pt + 1] = x1 + x_step * d1;
+          X[3 * (int64_t)pt + 2] = x2 + x_step * d2;
+        }
+      }
+    }
+#undef FZ_BS_FETCH
+    // the next run's window overwrites the records: every lane is done reading them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // partial results of the runs of one window, added in run order
@@ -599,6 +774,73 @@ static inline int check_launch_fz(const char* what) {
   return SFM_BA_OK;
 }
 
+#ifdef SFMBA_FZ_STAMPS
+static void fz_print_stamps() {
+  unsigned long long h[16];
+  (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fz_stamps), sizeof(h));
+  fprintf(stderr, "fz stamps (previous launch): setup %llu operands %llu valu %llu z %llu panel %llu fetch %llu mfma %llu tiles out %llu sums parked %llu added %llu rest %llu\n",
+          h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[10], h[7]);
+  memset(h, 0, sizeof(h));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fz_stamps), h, sizeof(h));
+}
+#endif
+// reduce and finish shared by the two kernels that produce the partial results
+static int launch_fused_tail(const sfm_ba_plan* p, double mu_u, double* S, double* e, double* part, double* kpart,
+                             hipStream_t st);
+
+bool fz_state_applies(const sfm_ba_plan* p) {
+  return p->n_runs > 0 && p->fz_enabled && p->fz_max_range_runs <= kFzMaxRunsPerRange;
+}
+
+int launch_assemble_state(const sfm_ba_plan* p, const double* blk, const double* P, const double* X, const double* xt,
+                          double mu, double mu_u, double* S, double* e, double* Vinv, double* eps_b, void* ws,
+                          hipStream_t st) {
+  if (!fz_state_applies(p)) return SFM_BA_EINVAL;
+  char* base = static_cast<char*>(ws);
+  double* part = reinterpret_cast<double*>(base + p->ws_fpart);
+  double* kpart = reinterpret_cast<double*>(base + p->ws_fkey);
+  {
+    ProfScope ps(KID_FUSED_STATE, st);
+    static const int wps_state = [] {
+      const char* v = getenv("SFM_BA_FZ_STATE_WPS");
+      return v && v[0] == '2' ? 2 : 1;
+    }();
+#define FZ_LAUNCH_STATE(W, T, E)                                                                                        \
+  do {                                                                                                                  \
+    if (wps_state == 2)                                                                                                 \
+      hipLaunchKernelGGL((k_fused_state<W, T, E, 2>), dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0,   \
+                         p->d_run_base, p->d_slot_obs, blk, P, X, xt, mu, Vinv, eps_b, part, p->fz_pmax, p->n, p->m);   \
+    else                                                                                                                \
+      hipLaunchKernelGGL((k_fused_state<W, T, E, 1>), dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0,   \
+                         p->d_run_base, p->d_slot_obs, blk, P, X, xt, mu, Vinv, eps_b, part, p->fz_pmax, p->n, p->m);   \
+  } while (0)
+    switch (p->fz_slots) {
+      case 4: FZ_LAUNCH_STATE(4, 2, 0); break;
+      case 5: FZ_LAUNCH_STATE(5, 3, 0); break;
+      case 6: FZ_LAUNCH_STATE(6, 3, 0); break;
+      case 7: FZ_LAUNCH_STATE(7, 3, 1); break;
+      default: FZ_LAUNCH_STATE(8, 4, 0); break;
+    }
+#undef FZ_LAUNCH_STATE
+  }
+#ifdef SFMBA_FZ_STAMPS
+  fz_print_stamps();
+#endif
+  const int rc = check_launch_fz("k_fused_state");
+  if (rc) return rc;
+  if (!S) return SFM_BA_OK;
+  return launch_fused_tail(p, mu_u, S, e, part, kpart, st);
+}
+
+int launch_back_substitute_state(const sfm_ba_plan* p, const double* blk, const double* Vinv, const double* eps_b,
+                                 const double* da, double* db, double* X, int update, double x_step, hipStream_t st) {
+  if (p->n_runs <= 0) return SFM_BA_EINVAL;
+  ProfScope ps(KID_BACK_STATE, st);
+  hipLaunchKernelGGL(k_back_substitute_state, dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0, p->d_run_base,
+                     p->d_slot_obs, blk, Vinv, eps_b, da, db, X, update, x_step, p->fz_pmax, p->n, p->m);
+  return check_launch_fz("k_back_substitute_state");
+}
+
 int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* xt, const double* xp,
                           const double* steps, double mu, double mu_u, double* S, double* e, double* Vinv,
                           double* eps_b, void* ws, hipStream_t st) {
@@ -606,7 +848,6 @@ int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* x
   char* base = static_cast<char*>(ws);
   double* part = reinterpret_cast<double*>(base + p->ws_fpart);
   double* kpart = reinterpret_cast<double*>(base + p->ws_fkey);
-  const int64_t stride = fz_part_stride(p->fz_slots);
   {
     ProfScope ps(KID_FUSED_RUNS, st);
 #define FZ_LAUNCH4(W, T, E, WPS, BL)                                                                             \
@@ -647,24 +888,23 @@ int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* x
 #undef FZ_LAUNCH4
   }
 #ifdef SFMBA_FZ_STAMPS
-  {
-    unsigned long long h[16];
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fz_stamps), sizeof(h));
-    fprintf(stderr, "fz stamps (previous launch): setup %llu operands %llu valu %llu z %llu panel %llu fetch %llu mfma %llu tiles out %llu sums parked %llu added %llu rest %llu\n",
-            h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[8], h[9], h[10], h[7]);
-    memset(h, 0, sizeof(h));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fz_stamps), h, sizeof(h));
-  }
+  fz_print_stamps();
 #endif
   int rc = check_launch_fz("k_fused_runs");
   if (rc) return rc;
   if (!S) return SFM_BA_OK;
+  return launch_fused_tail(p, mu_u, S, e, part, kpart, st);
+}
+
+static int launch_fused_tail(const sfm_ba_plan* p, double mu_u, double* S, double* e, double* part, double* kpart,
+                             hipStream_t st) {
+  const int64_t stride = fz_part_stride(p->fz_slots);
   {
     ProfScope ps(KID_FUSED_REDUCE, st);
     hipLaunchKernelGGL(k_fused_reduce, dim3(p->n_keys, 3), dim3(256), 0, st, p->d_key_ptr, p->d_key_run, stride, part,
                        kpart);
   }
-  rc = check_launch_fz("k_fused_reduce");
+  int rc = check_launch_fz("k_fused_reduce");
   if (rc) return rc;
   if (p->n_blocks > 0) {
     ProfScope ps(KID_FUSED_FINISH, st);

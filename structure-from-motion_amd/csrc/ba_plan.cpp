@@ -289,6 +289,8 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
         rng_run.assign(p->n_ranges + 1, n_runs);
         for (int32_t r = n_runs - 1; r >= 0; --r)
           if (run_pt0[r] % sh.pmax == 0) rng_run[run_pt0[r] / sh.pmax] = r;
+        for (int32_t g = 0; g < p->n_ranges; ++g)
+          p->fz_max_range_runs = std::max(p->fz_max_range_runs, rng_run[g + 1] - rng_run[g]);
         // steps of 8 points, run by run
         std::vector<int32_t> run_step0(n_runs + 1, 0);
         for (int32_t r = 0; r < n_runs; ++r) {

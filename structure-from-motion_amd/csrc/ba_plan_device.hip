@@ -649,6 +649,12 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
         SFMBA_HIP(hipMemcpyAsync(&n_steps, run_step0 + n_runs, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         SFMBA_HIP(hipStreamSynchronize(st));
         p->n_steps = n_steps;
+        {
+          std::vector<int32_t> rr((size_t)p->n_ranges + 1);
+          SFMBA_HIP(hipMemcpy(rr.data(), p->d_rng_run, sizeof(int32_t) * rr.size(), hipMemcpyDeviceToHost));
+          for (int32_t g = 0; g < p->n_ranges; ++g)
+            p->fz_max_range_runs = std::max(p->fz_max_range_runs, rr[(size_t)g + 1] - rr[(size_t)g]);
+        }
         SFMBA_TRY(keep(&p->d_step_pt0, n_steps, &bytes));
         SFMBA_TRY(keep(&p->d_step_run, n_steps + 1, &bytes));
         SFMBA_TRY(keep(&p->d_rng_step, p->n_ranges + 1, &bytes));

@@ -14,6 +14,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import numpy as np
 import torch
 
@@ -131,6 +133,7 @@ class DeviceProblem:
         # and the Jacobian and back-substitution kernels lose more than the assembly gains (measured
         # on 500 cameras x 300 000 points: 0.495 ms per iteration against 0.476 ms): off by default.
         self.use_steps = bool(steps)
+        self._want_state = os.environ.get("SFM_BA_STATE", "1") != "0"
         self.group = group
         self.world = 1
         if group is not None:
@@ -161,6 +164,9 @@ class DeviceProblem:
             raise AssertionError("index lists do not cover every camera / point")
         # band of the reduced camera matrix: the widest over all shards
         self.half_bandwidth = self.plan.half_bandwidth
+        # rows of A formed inside the kernels that use them (plans with runs)
+        self.from_state = (self._want_state and not self.use_steps
+                           and bool(self.lib.sfm_ba_plan_state_path(self.plan.handle)))
         if self.sharded and self.world > 1:
             import torch.distributed as dist
 
@@ -278,6 +284,28 @@ class DeviceProblem:
         _lib.check(self.lib.sfm_ba_jacobian(p(self.cam_blk), p(self.P), p(self.X), p(self.cam_idx), p(self.pt_idx),
                                             self.N, None, None, p(self.x_pred), _stream()))
 
+    def assemble_state(self, mu):
+        """Jacobian blocks and Schur assembly in one pass (plans with runs): the rows of A are formed
+        inside the assembly kernel from the camera records and the points and never written."""
+        p = _lib.ptr
+        mu_u = 0.0 if self.sharded else mu
+        n7 = self.n7
+        self._packed_mu = float(mu) if self.band_sharded else None
+        _lib.check(self.lib.sfm_ba_schur_assemble_state(
+            self.plan.handle, p(self.cam_blk), p(self.P), p(self.X), p(self.x_true), float(mu), float(mu_u),
+            p(self.S), p(self.e), p(self.V_inv), p(self.eps_b), p(self.workspace), _stream()))
+        if self.band_sharded:
+            _lib.check(self.lib.sfm_ba_band_compact(p(self.S), n7, self.half_bandwidth, p(self.compact), _stream()))
+            self._all_reduce(self.compact)
+            _lib.check(self.lib.sfm_ba_band_expand(p(self.compact), n7, self.half_bandwidth, p(self.packed), _stream()))
+
+    def back_substitute_state(self, update_points=False):
+        """delta_b (and the point update) with the rows of A formed again from the state."""
+        p = _lib.ptr
+        _lib.check(self.lib.sfm_ba_back_substitute_state(
+            self.plan.handle, p(self.cam_blk), p(self.V_inv), p(self.eps_b), p(self.delta_a), p(self.delta_b),
+            p(self.X), 1 if update_points else 0, float(self.X_STEP), _stream()))
+
     def assemble(self, mu, weights=None, x_true=None, x_pred=None, A=None, B=None, by_products=True,
                  reduce_packed=False, steps=False):
         """``by_products=False`` skips U and eps_a (the solve needs only S and e): the library then
@@ -392,7 +420,12 @@ class DeviceProblem:
         mu = self.MU if mu is None else mu
         if not self._blk_fresh:
             self.camera_prepare()
-        if self.plan.fused and self.steps is not None and mu > 0:
+        if self.from_state and self.plan.fused and mu > 0:
+            # plans with runs: the rows of A are formed inside the assembly and the back-substitution
+            self.assemble_state(mu)
+            self.solve()
+            self.back_substitute_state(update_points=True)
+        elif self.plan.fused and self.steps is not None and mu > 0:
             # plans with runs: A and the residuals never exist in the caller's order
             self.jacobian_steps()
             self.assemble(mu, reduce_packed=True, steps=True)
