@@ -286,14 +286,12 @@ __device__ __forceinline__ double fz_rcp(double x) {
 // (12) in LDS, with one reciprocal per quotient rule instead of fourteen divisions (a few units in
 // the last place from the rows k_jacobian writes).  av[0..6] = row of A as k_jacobian lays it out,
 // av[7] = x_true - x_pred; zeros for a lane without an observation.
-template <bool RESIDUAL = true, bool FENCED = false>
-__device__ __forceinline__ void fz_rows_from_state(const double* __restrict__ rec, const double* __restrict__ pm,
-                                                   double x0, double x1, double x2, double2 xt, bool has,
-                                                   double2 (&av)[9]) {
+template <bool RESIDUAL = true, bool FENCED = false, typename RecT = const double2*, typename PmT = const double2*>
+__device__ __forceinline__ void fz_rows_from_state(RecT r2, PmT p2, double x0, double x1, double x2, double2 xt,
+                                                   bool has, double2 (&av)[9]) {
   // (FENCED: in four parts fenced off from each other.  Left alone, the scheduler moves all 34 LDS reads
   // to the front: 68 registers, which a kernel compiled for two waves per SIMD does not have to spare;
   // a kernel with one wave per SIMD wants exactly that, nothing else hides the latency of the reads)
-  const double2* r2 = reinterpret_cast<const double2*>(rec);
   const double z = 0.0;
   double d0, d1, d2, wi, ui, vi;
   {
@@ -322,6 +320,27 @@ __device__ __forceinline__ void fz_rows_from_state(const double* __restrict__ re
   }
   if (FENCED) __builtin_amdgcn_sched_barrier(0);
   const double2 f01 = r2[26], f23 = r2[27];  // fx fy | ox oy
+  if (FENCED) {
+    // one column of the 9 x 4 table dR/dQ at a time (entry (3 r + i, q) at doubles 12 + 4 (3 r + i) + q):
+    // nine 8-byte reads in flight instead of eighteen 16-byte ones
+    const double* rd = reinterpret_cast<const double*>(&r2[0]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double g[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        g[r] = d0 * rd[12 + 4 * (3 * r + 0) + q] + d1 * rd[12 + 4 * (3 * r + 1) + q] + d2 * rd[12 + 4 * (3 * r + 2) + q];
+      const double du = f01.x * g[0] + f23.x * g[2];
+      const double dv = f01.y * g[1] + f23.y * g[2];
+      const double a0 = fma(wi, du, -ui * g[2]);
+      const double a1 = fma(wi, dv, -vi * g[2]);
+      if (q == 0) { av[0].x = a0; av[3].y = a1; }
+      if (q == 1) { av[0].y = a0; av[4].x = a1; }
+      if (q == 2) { av[1].x = a0; av[4].y = a1; }
+      if (q == 3) { av[1].y = a0; av[5].x = a1; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     // columns 2 h, 2 h + 1 of the 9 x 4 table dR/dQ: row 3 r + i at doubles 12 + 4 (3 r + i)
@@ -349,10 +368,9 @@ __device__ __forceinline__ void fz_rows_from_state(const double* __restrict__ re
       av[4].y = a1[0];
       av[5].x = a1[1];
     }
-    if (FENCED) __builtin_amdgcn_sched_barrier(0);
+  }
   }
   if (RESIDUAL) {
-    const double2* p2 = reinterpret_cast<const double2*>(pm);
     const double2 p01 = p2[0], p23 = p2[1], p45 = p2[2], p67 = p2[3], p89 = p2[4], pab = p2[5];
     const double h0 = p01.x * x0 + p01.y * x1 + p23.x * x2 + p23.y;
     const double h1 = p45.x * x0 + p45.y * x1 + p67.x * x2 + p67.y;
@@ -443,6 +461,27 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
     X2 = xp_[2];                                                           \
     XT = ldg2(xt + 2 * (int64_t)((pos_) >= 0 ? (pos_) : 0));               \
   } while (0)
+  // With one wave per SIMD (512 registers) the lane keeps its camera's record and projection matrix
+  // in registers for the whole run: they change with the window only.  With two waves per SIMD they
+  // are read from LDS at every step.
+  double2 rreg[WPS == 1 ? 28 : 1], preg[WPS == 1 ? 6 : 1];
+#define FZ_RECORD_TO_REGS()                                                                                 \
+  do {                                                                                                      \
+    if (WPS == 1) {                                                                                         \
+      const double2* r_ = reinterpret_cast<const double2*>(sRec + RS * s);                                  \
+      const double2* q_ = reinterpret_cast<const double2*>(sRec + 8 * RS + 12 * s);                         \
+      _Pragma("unroll") for (int i_ = 0; i_ < 28; ++i_) rreg[WPS == 1 ? i_ : 0] = r_[i_];                   \
+      _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) preg[WPS == 1 ? i_ : 0] = q_[i_];                    \
+    }                                                                                                       \
+  } while (0)
+#define FZ_ROWS(X0, X1, X2, XT, HAS)                                                                        \
+  do {                                                                                                      \
+    if (WPS == 1)                                                                                           \
+      fz_rows_from_state<true, false>(rreg, preg, X0, X1, X2, XT, HAS, av);                                 \
+    else                                                                                                    \
+      fz_rows_from_state<true, true>(reinterpret_cast<const double2*>(sRec + RS * s),                       \
+                                     reinterpret_cast<const double2*>(sRec + 8 * RS + 12 * s), X0, X1, X2, XT, HAS, av); \
+  } while (0)
   const int pt_first = f0 + p < n_pts ? f0 + p : n_pts - 1;
   const int pos_raw = slot_obs[(unsigned)(kFzLanesPerPoint * pt_first + s)];
   for (int i = lane; i <= nr; i += 64) bnd[i] = run_pt0[run0 + i];
@@ -454,10 +493,11 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
   int pos = f0 + p < FZ_LIM(0) ? pos_raw : -1;
   int r_win = 0;  // run whose window sits in LDS
   FZ_LOAD_WINDOW(0);
+  FZ_RECORD_TO_REGS();
   double xn0, xn1, xn2;
   double2 xtn;
   FZ_FETCH_STATE(f0, pos, xn0, xn1, xn2, xtn);
-  fz_rows_from_state<true, WPS == 2>(sRec + RS * s, sRec + 8 * RS + 12 * s, xn0, xn1, xn2, xtn, pos >= 0, av);
+  FZ_ROWS(xn0, xn1, xn2, xtn, pos >= 0);
   int f1 = f0, r1 = r0;
   FZ_ADVANCE(f1, r1);
   int pos_next = r1 < nr ? FZ_FETCH_POS(f1, FZ_LIM(r1)) : -1;
@@ -487,8 +527,10 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
   do {
     const int pt = f0 + p;
     const int pt1 = FZ_LIM(r0);
-    // the next step's point and pixel: on their way during this step's arithmetic
-    if (r1 < nr) FZ_FETCH_STATE(f1, pos_next, xn0, xn1, xn2, xtn);
+    // the next step's point and pixel: on their way during this step's arithmetic (with two waves per
+    // SIMD the five values would not fit into the registers across it: fetched where they are used,
+    // and the other wave covers the wait)
+    if (WPS == 1 && r1 < nr) FZ_FETCH_STATE(f1, pos_next, xn0, xn1, xn2, xtn);
     FZ_STAMP(1);
 #include "ba_fused_step_a.inc"
     FZ_STAMP(3);
@@ -499,11 +541,13 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
     __builtin_amdgcn_sched_barrier(0);
     pos = pos_next;
     if (r0 < nr) {
+      if (WPS != 1) FZ_FETCH_STATE(f0, pos, xn0, xn1, xn2, xtn);
       if (r0 != r_win) {
         FZ_LOAD_WINDOW(r0);
+        FZ_RECORD_TO_REGS();
         r_win = r0;
       }
-      fz_rows_from_state<true, WPS == 2>(sRec + RS * s, sRec + 8 * RS + 12 * s, xn0, xn1, xn2, xtn, pos >= 0, av);
+      FZ_ROWS(xn0, xn1, xn2, xtn, pos >= 0);
     }
     f1 = f2; r1 = r2;
     pos_next = pos_next2;
@@ -518,6 +562,8 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
   FZ_STAMP_FLUSH;
 #undef FZ_FETCH_POS
 #undef FZ_FETCH_STATE
+#undef FZ_ROWS
+#undef FZ_RECORD_TO_REGS
 #undef FZ_LOAD_WINDOW
 #undef FZ_ADVANCE
 #undef FZ_LIM
@@ -594,7 +640,8 @@ __global__ __launch_bounds__(64) void k_back_substitute_state(
         for (int i = 0; i < 3; ++i) eb[i] = eps_b[3 * (int64_t)pt + i];
       }
       double2 av[9];
-      fz_rows_from_state<false>(sRec + REC * s, nullptr, x0, x1, x2, make_double2(0.0, 0.0), pos >= 0, av);
+      fz_rows_from_state<false>(reinterpret_cast<const double2*>(sRec + REC * s), static_cast<const double2*>(nullptr), x0,
+                                x1, x2, make_double2(0.0, 0.0), pos >= 0, av);
 #define a_(i) (((i) & 1) ? av[(i) >> 1].y : av[(i) >> 1].x)
       const double* dj = sDa + 7 * s;
       double h0 = 0.0, h1 = 0.0;
@@ -801,10 +848,15 @@ int launch_assemble_state(const sfm_ba_plan* p, const double* blk, const double*
   double* kpart = reinterpret_cast<double*>(base + p->ws_fkey);
   {
     ProfScope ps(KID_FUSED_STATE, st);
-    static const int wps_state = [] {
+    // waves per SIMD: with windows of up to six cameras the kernel fits 256 registers (what it spills
+    // is only reloaded when the window changes) and two waves cover each other's waits (364 against
+    // 387 us on 1 800 x 1 M); from seven cameras on it spills inside the steps, and one wave with 512
+    // registers - the camera record held in them for the whole run - is the faster one (142 against 147 us)
+    static const int wps_env = [] {
       const char* v = getenv("SFM_BA_FZ_STATE_WPS");
-      return v && v[0] == '2' ? 2 : 1;
+      return v && (v[0] == '1' || v[0] == '2') ? v[0] - '0' : 0;
     }();
+    const int wps_state = wps_env ? wps_env : (p->fz_slots <= 6 ? 2 : 1);
 #define FZ_LAUNCH_STATE(W, T, E)                                                                                        \
   do {                                                                                                                  \
     if (wps_state == 2)                                                                                                 \
