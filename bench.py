@@ -290,8 +290,15 @@ def stage_groups(prof, steps, N, n, m, s_blocks, pmc):
     """Per-stage record: time, the bytes the loop must move (headline GB/s) and the same with B priced
     as a materialised array, counter traffic where a PMC pass of these kernels is on file."""
     alg, alg_b = algorithmic_bytes(N, n, m, s_blocks), algorithmic_bytes(N, n, m, s_blocks, with_B=True)
+    stages = dict(GROUPS)
+    if "k_fused_state" in prof and "k_jacobian" not in prof:
+        # the rows of A are formed inside the assembly kernel: one stage does the work of two, and is
+        # priced with the bytes of both (what the two stages would have to move between them)
+        stages = {"jacobian+assembly": GROUPS["assembly"], "back_substitution": GROUPS["back_substitution"]}
+        for d in (alg, alg_b):
+            d["jacobian+assembly"] = d["jacobian"] + d["assembly"]
     groups = {}
-    for g, names in GROUPS.items():
+    for g, names in stages.items():
         present = [nm for nm in names if nm in prof]
         ms = sum(prof[nm][0] for nm in present) / steps
         traffic = None
@@ -475,10 +482,13 @@ def main():
             "achieved_with_B": groups[dominant]["GBps_with_B"],
             "frac_with_B": groups[dominant]["GBps_with_B"] / HBM_PEAK_GBS,
             "groups": groups,
-            "note": "achieved / frac and every group's GBps price the bytes the loop has to move: 136 / 152 / 120 "
-                    "bytes per observation for Jacobian / assembly / back-substitution (dF/dX = -dF/dC is read from "
-                    "the rows of A, B is never written); the *_with_B fields add B as a materialised array "
-                    "(184 / 200 / 168), the form in which the reference hands the blocks between its stages",
+            "note": "achieved / frac and every group's GBps price the algorithmic bytes of the stages: 136 / 152 / 120 "
+                    "bytes per observation for Jacobian / assembly / back-substitution (B = -dF/dC is part of the rows "
+                    "of A and never written); the *_with_B fields add B as a materialised array (184 / 200 / 168), the "
+                    "form in which the reference hands the blocks between its stages.  Where one kernel forms the rows "
+                    "of A and assembles from them (jacobian+assembly) it is priced with the bytes of both stages; its "
+                    "real traffic (the traffic field) is far smaller, because A never goes to memory, and what "
+                    "bounds it is the fp64 pipe, not HBM",
         }
         n7 = 7 * m
         out = {
@@ -503,7 +513,8 @@ def main():
                                else f"one problem sharded by point id over {world} GPU(s)"),
                 "cameras": m, "points": n_total, "observations": N_total, "visibility": args.visibility,
                 "nonzero_S_blocks": s_blocks,
-                "assembly": "fused point-major" if prob.plan.fused else "camera-pair",
+                "assembly": ("fused point-major, rows of A formed in the kernel" if prob.from_state and prob.plan.fused
+                             else "fused point-major" if prob.plan.fused else "camera-pair"),
                 "parallelism": "1 gpu" if world == 1 else f"point-id sharding x{world}, all-reduce of "
                                f"{packed_system_elements(m, prob.half_bandwidth) * 8 / 1e6:.1f} MB per iteration",
             },

@@ -125,7 +125,7 @@ class DeviceProblem:
     X_STEP = 0.5   # :100
 
     def __init__(self, K, R, T, X, cam_idx, pt_idx, x_true, n_cams=None, group=None, check=True, device=None,
-                 sharded=None, plan_where="device", steps=False):
+                 sharded=None, plan_where="device", steps=False, state=None):
         self.lib = _lib.load()
         self.device = _dev(device)
         # steps: keep the rows of A as step blocks (plans with runs only).  The assembly kernel then
@@ -133,7 +133,9 @@ class DeviceProblem:
         # and the Jacobian and back-substitution kernels lose more than the assembly gains (measured
         # on 500 cameras x 300 000 points: 0.495 ms per iteration against 0.476 ms): off by default.
         self.use_steps = bool(steps)
-        self._want_state = os.environ.get("SFM_BA_STATE", "1") != "0"
+        # state: form the rows of A inside the assembly and back-substitution kernels instead of
+        # writing A once and reading it twice (plans with runs; default on, SFM_BA_STATE=0 turns it off)
+        self._want_state = (os.environ.get("SFM_BA_STATE", "1") != "0") if state is None else bool(state)
         self.group = group
         self.world = 1
         if group is not None:

@@ -128,10 +128,12 @@ def test_fused_iteration_against_oracle(m, n, k):
     R, T, X = p.R.copy(), p.T.copy(), p.X.copy()
     ref = [orc.gn_iteration_arrays(p.K, R, T, X, p.cam_idx, p.pt_idx, p.x_true) for _ in range(2)]
     costs = {}
-    for fused in (1, 0, 2):  # 2: the fused assembly on step blocks
-        prob = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true, steps=(fused == 2))
-        assert prob.plan.fused == 1
-        prob.plan.set_fused(fused)
+    # 1: rows of A formed inside the fused kernels; 0: camera-pair path; 2: fused assembly on step
+    # blocks; 3: fused assembly on the rows of A written by the Jacobian kernel
+    for fused in (1, 0, 2, 3):
+        prob = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true, steps=(fused == 2), state=(fused == 1))
+        assert prob.plan.fused == 1 and prob.from_state == (fused == 1)
+        prob.plan.set_fused(0 if fused == 0 else 1)
         costs[fused] = []
         for it in range(2):
             c_ref, da_ref, db_ref = ref[it]
@@ -144,8 +146,8 @@ def test_fused_iteration_against_oracle(m, n, k):
             assert relerr(prob.delta_a.cpu().numpy(), da_ref) < 1e-7
             assert relerr(prob.delta_b.cpu().numpy(), db_ref) < 1e-7
         assert relerr(prob.points(), X) < 1e-8
-    for a, b, c in zip(costs[0], costs[1], costs[2]):
-        assert abs(a - b) <= 1e-9 * a and abs(a - c) <= 1e-9 * a, costs
+    for a, b, c, d in zip(costs[0], costs[1], costs[2], costs[3]):
+        assert abs(a - b) <= 1e-9 * a and abs(a - c) <= 1e-9 * a and abs(a - d) <= 1e-9 * a, costs
 
 
 def test_ineligible_patterns_keep_the_pair_path():
