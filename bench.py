@@ -490,6 +490,20 @@ def main():
                     "real traffic (the traffic field) is far smaller, because A never goes to memory, and what "
                     "bounds it is the fp64 pipe, not HBM",
         }
+        if prob.plan.fused and ("k_fused_state" in prof or "k_fused_runs" in prof):
+            # the fused kernel is bound by the fp64 pipe (matrix and vector instructions share it), not by
+            # HBM: matrix-instruction flops it executes per launch, exactly, against the fp64 peak
+            kn = "k_fused_state" if "k_fused_state" in prof else "k_fused_runs"
+            slots = prob.plan.fused_slots
+            tiles = 2 if slots <= 4 else (3 if slots <= 7 else 4)
+            mfma_flops = prob.plan.n_steps * (tiles * (tiles + 1) // 2) * 6 * 2048.0
+            t = prof[kn][0] / prof[kn][1] * 1e-3
+            roofline["fp64_pipe"] = {
+                "kernel": kn, "matrix_flops": mfma_flops, "achieved": mfma_flops / t / 1e12, "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": mfma_flops / t / 1e12 / FP64_PEAK_TFLOPS,
+                "note": "v_mfma_f64_16x16x4 flops only (tiles x 6 per step of 8 points); the same pipe also executes "
+                        "the kernel's vector fp64 arithmetic, about as many cycles again",
+            }
         n7 = 7 * m
         out = {
             "metric": "BA Gauss-Newton observations/sec (synthetic %d cams x %d pts)" % (m, n_total),

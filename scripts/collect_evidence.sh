@@ -4,7 +4,7 @@
 set -e
 RUN=$1; RT=$2
 cd "$(dirname "$0")/.."
-cp gpurun_out/prof_${RUN}/*/*kernel_stats.csv profiles/${RT}_c4_banded_kernel_stats.csv
+cp "$(ls -t gpurun_out/prof_${RUN}/*/*kernel_stats.csv | head -1)" profiles/${RT}_c4_banded_kernel_stats.csv
 cp gpurun_out/${RUN}_prof_summary.txt profiles/${RT}_c4_banded_kernel_summary.txt
 for n in c4_banded c4_uniform venice_banded; do
   cp gpurun_out/${RUN}_${n}_pmc_fetch.txt profiles/${RT}_${n}_pmc_fetch_size.txt
