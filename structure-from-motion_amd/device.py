@@ -422,7 +422,7 @@ class DeviceProblem:
         mu = self.MU if mu is None else mu
         if not self._blk_fresh:
             self.camera_prepare()
-        if self.from_state and self.plan.fused and mu > 0:
+        if self.from_state and self.plan.fused and mu > 0 and (not self.sharded or self.band_sharded):
             # plans with runs: the rows of A are formed inside the assembly and the back-substitution
             self.assemble_state(mu)
             self.solve()
