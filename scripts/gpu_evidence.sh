@@ -21,6 +21,10 @@ pmc_pair c4_banded c4_500x300k/banded || exit 3
 pmc_pair c4_uniform c4_500x300k/uniform --visibility uniform || exit 3
 pmc_pair venice_banded venice1800/banded --workload venice1800 || exit 3
 timeout -k 10 300 python3 bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err || exit 1
+# the same line with the rows of A written by the Jacobian kernel and read back twice (the loop's form before
+# the rows were formed inside the kernels): three separate stages, priced separately
+SFM_BA_STATE=0 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-uniform-record > gpurun_out/${TAG}_bench_default_rows.json 2> gpurun_out/${TAG}_bench_default_rows.err || exit 1
+SFM_BA_STATE=0 timeout -k 10 300 python3 bench.py --workload venice1800 --no-cpu-baseline --no-uniform-record > gpurun_out/${TAG}_bench_venice1800_banded_rows.json 2> gpurun_out/${TAG}_bench_venice1800_banded_rows.err || exit 1
 for W in "ladybug50 banded" "ladybug50 uniform" "c4_500x300k uniform" "venice1800 banded" "venice1800 uniform"; do
   set -- $W
   timeout -k 10 500 python3 bench.py --workload $1 --visibility $2 --no-cpu-baseline --no-uniform-record > gpurun_out/${TAG}_bench_$1_$2.json 2> gpurun_out/${TAG}_bench_$1_$2.err || exit 5

@@ -17,9 +17,11 @@ def bench(name):
     return json.loads(open(path).read().strip().splitlines()[-1])
 
 
-rows = [("default", "c4_500x300k banded (the `bench.py` default)"), ("c4_500x300k_uniform", "c4_500x300k uniform"),
+rows = [("default", "c4_500x300k banded (the `bench.py` default)"),
+        ("default_rows", "c4_500x300k banded, rows of A materialised (`SFM_BA_STATE=0`)"), ("c4_500x300k_uniform", "c4_500x300k uniform"),
         ("ladybug50_banded", "ladybug50 banded"), ("ladybug50_uniform", "ladybug50 uniform"),
-        ("venice1800_banded", "venice1800 banded"), ("venice1800_uniform", "venice1800 uniform (dense S, 12 600 unknowns)")]
+        ("venice1800_banded", "venice1800 banded"),
+        ("venice1800_banded_rows", "venice1800 banded, rows of A materialised (`SFM_BA_STATE=0`)"), ("venice1800_uniform", "venice1800 uniform (dense S, 12 600 unknowns)")]
 out = [f"# profiles — round {tag[1:]} evidence (MI355X, one GPU)", "",
        "Produced by `bash scripts/gpu_evidence.sh <tag>` on the GPU box; this file is generated from the files next to it",
        "by `scripts/make_profiles_readme.py`.", "",

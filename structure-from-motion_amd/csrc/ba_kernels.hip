@@ -1291,18 +1291,45 @@ __global__ __launch_bounds__(kCamThreads) void k_cost_items(
   __shared__ double red[kCamThreads];
   const int t = threadIdx.x;
   const int beg = item_beg[blockIdx.x], end = item_end[blockIdx.x];
+  // every observation of an item belongs to one camera: its projection matrix through the scalar path
+  const int64_t pos0 = cam_obs ? cam_obs[beg] : beg;
+  const double* pm = P + 12 * (int64_t)__builtin_amdgcn_readfirstlane(cam[pos0]);
+  double pr[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) pr[i] = pm[i];
+  // the (at most kCamChunk / kCamThreads) observations of a thread: all index loads, then all gathers,
+  // then the arithmetic, summed in the order of the observations
+  constexpr int U = kCamChunk / kCamThreads;
+  int64_t pos[U];
+  bool on[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int i = beg + t + u * kCamThreads;
+    on[u] = i < end;
+    pos[u] = on[u] ? (cam_obs ? cam_obs[i] : i) : pos0;
+  }
+  int pts[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) pts[u] = pt[pos[u]];
+  double xs[U][3];
+  double2 xa[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const double* x = X + 3 * (int64_t)pts[u];
+    xs[u][0] = x[0];
+    xs[u][1] = x[1];
+    xs[u][2] = x[2];
+    xa[u] = ld2(xt + 2 * pos[u]);
+  }
   double acc = 0.0;
-  for (int i = beg + t; i < end; i += kCamThreads) {
-    const int64_t pos = cam_obs ? cam_obs[i] : i;
-    const double* pm = P + 12 * (int64_t)cam[pos];
-    const double* x = X + 3 * (int64_t)pt[pos];
-    const double x0 = x[0], x1 = x[1], x2 = x[2];
-    const double h0 = pm[0] * x0 + pm[1] * x1 + pm[2] * x2 + pm[3];
-    const double h1 = pm[4] * x0 + pm[5] * x1 + pm[6] * x2 + pm[7];
-    const double h2 = pm[8] * x0 + pm[9] * x1 + pm[10] * x2 + pm[11];
-    const double2 xa = ld2(xt + 2 * pos);
-    const double e0 = xa.x - h0 / h2, e1 = xa.y - h1 / h2;
-    acc += e0 * e0 + e1 * e1;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const double x0 = xs[u][0], x1 = xs[u][1], x2 = xs[u][2];
+    const double h0 = pr[0] * x0 + pr[1] * x1 + pr[2] * x2 + pr[3];
+    const double h1 = pr[4] * x0 + pr[5] * x1 + pr[6] * x2 + pr[7];
+    const double h2 = pr[8] * x0 + pr[9] * x1 + pr[10] * x2 + pr[11];
+    const double e0 = xa[u].x - h0 / h2, e1 = xa[u].y - h1 / h2;
+    if (on[u]) acc += e0 * e0 + e1 * e1;
   }
   red[t] = acc;
   __syncthreads();
