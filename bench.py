@@ -339,7 +339,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None,
                     help="default: c4_500x300k (weak scaling), venice1800 (strong scaling)")
-    ap.add_argument("--visibility", default="banded", choices=["banded", "uniform"])
+    ap.add_argument("--visibility", default="banded", choices=["banded", "uniform", "closures"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's point count per GPU; strong: one problem sharded over the GPUs")
     ap.add_argument("--seed", type=int, default=0)

@@ -72,7 +72,7 @@ def _views(rng, m: int, n: int, k, visibility: str) -> tuple[np.ndarray, np.ndar
     kmax = int(kk.max())
     if kmax > m:
         raise ValueError("views per point exceeds number of cameras")
-    if visibility == "banded":
+    if visibility in ("banded", "closures"):
         # k consecutive cameras from a random start (no wrap-around: S is block-banded).  Point
         # ids ascend with the first observing camera, as they do in the incremental pipeline
         # that feeds the reference's BA: new points are appended to the map when a frame is
@@ -82,6 +82,18 @@ def _views(rng, m: int, n: int, k, visibility: str) -> tuple[np.ndarray, np.ndar
         start, kk = start[order], kk[order]
         offs = np.arange(kmax)[None, :]
         cams = start[:, None] + offs
+        if visibility == "closures":
+            # a sequence that comes back to places it has seen: one point in a thousand keeps the
+            # first half of its views and takes the other half from cameras half a sequence away,
+            # so S gains blocks far from the diagonal and is no longer block-tridiagonal
+            if m < 4 * kmax:
+                raise ValueError("closures need at least four times as many cameras as views per point")
+            far = np.zeros(n, dtype=bool)
+            far[rng.choice(n, size=max(1, n // 1000), replace=False)] = True
+            half = (kk + 1) // 2
+            jump = (start + m // 2) % (m - kmax + 1) - start
+            moved = far[:, None] & (offs >= half[:, None])
+            cams = np.where(moved, cams + jump[:, None], cams)
     elif visibility == "uniform":
         # random k-subset of the m cameras per point: draw k cameras, redraw the
         # rows that hold a duplicate until none is left (k << m in every workload)

@@ -267,9 +267,11 @@ def test_error_cases(ba):
     assert outcome(lambda: SBA(vi2, pi2).compute(x2, x2 * 0.5, A2, B2, mu=0.5))[0] is None
 
 
-@pytest.mark.parametrize("visibility", ["uniform", "banded"])
+@pytest.mark.parametrize("visibility", ["uniform", "banded", "closures"])
 def test_ladybug_scale_against_oracle(ba, visibility):
     """50 cameras x 20k points x 160k observations, two iterations, against the CPU oracle.
+    ("closures": banded, with one point in a thousand also seen half a sequence away, so S is a
+    band plus far blocks and goes through the general Cholesky with its zero tiles skipped.)
 
     At this size cond(S) is 1.4e9-2e9 and numpy's LU solution of S delta_a = e (what the
     reference and the oracle use) is itself 1e-9 relative away from the exact solution

@@ -121,3 +121,18 @@ def test_forced_sharded_flow_single_rank():
             assert np.max(np.abs(a.points() - b.points())) < 1e-10
     finally:
         dist.destroy_process_group()
+
+
+def test_rccl_group_of_one_rank():
+    """The collectives of the sharded flow through RCCL on device buffers.  The test box has one
+    GPU and RCCL takes one rank per device, so the group has one rank: what is checked is that
+    the device tensors go to RCCL as they lie and the flow equals the unsharded one, for the packed
+    band exchange and for the lower-triangle exchange.  Runs in a child process, which ends with
+    its process group."""
+    import subprocess
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + (os.getpid() % 500)))
+    r = subprocess.run([sys.executable, "-u", os.path.join(ROOT, "scripts", "probes", "rccl_one_rank.py")],
+                       capture_output=True, text=True, timeout=200, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "band exchange" in r.stdout and "triangle exchange" in r.stdout and "rccl one-rank ok" in r.stdout

@@ -33,3 +33,28 @@ def checker(tmp_path_factory):
 def test_plan_invariants(checker, args):
     out = subprocess.run([checker] + [str(a) for a in args], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+
+
+def test_closures_visibility():
+    """Banded visibility with loop closures: same observation count per point as the banded mode,
+    every point seen once per camera, and one point in a thousand spans about half the sequence."""
+    import numpy as np
+
+    import sfm_amd  # noqa: F401
+    from sfm_amd import synthetic
+
+    p = synthetic.make_problem(80, 6000, (4, 6), visibility="closures", seed=3)
+    key = p.pt_idx.astype(np.int64) * p.m + p.cam_idx
+    assert np.unique(key).size == p.n_obs
+    assert np.all(np.diff(p.cam_idx) >= 0)
+    order = np.lexsort((p.cam_idx, p.pt_idx))
+    pt, cam = p.pt_idx[order], p.cam_idx[order]
+    b = np.searchsorted(pt, np.arange(p.n + 1))
+    k = np.diff(b)
+    assert k.min() >= 4 and k.max() <= 6
+    span = np.maximum.reduceat(cam, b[:-1]) - np.minimum.reduceat(cam, b[:-1]) + 1
+    far = span > 6
+    assert far.sum() == p.n // 1000
+    assert np.all(span[far] >= 80 // 2 - 6)
+    with pytest.raises(ValueError):
+        synthetic.make_problem(12, 100, 4, visibility="closures")
