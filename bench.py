@@ -315,13 +315,21 @@ def stage_groups(prof, steps, N, n, m, s_blocks, pmc):
 
 def solve_record(prof, steps, n7, hb):
     solve_ms = prof.get("solve_reduced", (0.0, 1))[0] / steps
+    # superblock edge of the wide-band reduction (the library's rule: the band fits one superblock and
+    # there are enough superblocks for the rounds to beat the general path's panel chain)
+    wide = 128 if 64 < hb <= 128 and -(-n7 // 128) >= 8 else 256 if 128 < hb <= 256 and -(-n7 // 256) >= 13 else 0
+    if os.environ.get("SFM_BA_WIDE_BAND") == "0":
+        wide = 0
     if hb <= 64:
         # band Cholesky + two band substitutions
         flops, path = n7 * (hb + 1.0) ** 2 + 4.0 * n7 * (hb + 1.0), "block cyclic reduction (band)"
+    elif wide:
+        flops = n7 * (hb + 1.0) ** 2 + 4.0 * n7 * (hb + 1.0)
+        path = f"block cyclic reduction on superblocks of {wide} unknowns (band)"
     else:
         flops, path = n7 ** 3 / 3.0 + 2.0 * n7 * n7, "blocked Cholesky (dense)"
     return {
-        "bound": "latency" if hb <= 64 else "mfma",
+        "bound": "latency" if hb <= 64 or wide else "mfma",
         "path": path,
         "half_bandwidth": hb,
         "flops": flops,
@@ -339,7 +347,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None,
                     help="default: c4_500x300k (weak scaling), venice1800 (strong scaling)")
-    ap.add_argument("--visibility", default="banded", choices=["banded", "uniform", "closures"])
+    ap.add_argument("--visibility", default="banded", choices=["banded", "uniform", "closures", "loop"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's point count per GPU; strong: one problem sharded over the GPUs")
     ap.add_argument("--seed", type=int, default=0)
@@ -427,7 +435,10 @@ def main():
     prob = DeviceProblem(prob_h.K, prob_h.R, prob_h.T, prob_h.X, prob_h.cam_idx, prob_h.pt_idx, prob_h.x_true,
                          n_cams=m, group=group, check=(world == 1),
                          plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"),
-                         steps=bool(int(os.environ.get("SFM_BA_STEPS", "0"))))
+                         steps=bool(int(os.environ.get("SFM_BA_STEPS", "0"))),
+                         # sequences that revisit places: cameras in the folded order (one GPU only)
+                         reorder=(world == 1 and args.visibility in ("loop", "closures")
+                                  and os.environ.get("SFM_BA_REORDER", "1") != "0"))
     N_loc, n_loc = prob.N, prob.n
 
     def barrier():
@@ -527,6 +538,9 @@ def main():
                                else f"one problem sharded by point id over {world} GPU(s)"),
                 "cameras": m, "points": n_total, "observations": N_total, "visibility": args.visibility,
                 "nonzero_S_blocks": s_blocks,
+                "camera_order": ("acquisition order" if prob.cam_order is None else
+                                 f"folded (half bandwidth {prob.natural_half_bandwidth} in acquisition order, "
+                                 f"{prob.half_bandwidth} on the device)"),
                 "assembly": ("fused point-major, rows of A formed in the kernel" if prob.from_state and prob.plan.fused
                              else "fused point-major" if prob.plan.fused else "camera-pair"),
                 "parallelism": "1 gpu" if world == 1 else f"point-id sharding x{world}, all-reduce of "

@@ -273,8 +273,10 @@ int sfm_ba_solve_reduced(double* d_S, int32_t n7, double* d_delta_a, void* d_cho
 /* The same solve (src/sparse_ba.py:274-276) for a caller that knows S[r][c] = 0 wherever
  * |r - c| > half_bandwidth (sfm_ba_plan_half_bandwidth).  With half_bandwidth <= 64 the factorisation
  * is a chain of 64 x 64 blocks that one workgroup walks in a single launch, substitutions included,
- * and d_S is only read; wider bands take the general path of sfm_ba_solve_reduced (d_S destroyed).
- * Entries outside the stated band are never read on the narrow path. */
+ * and d_S is only read; with 64 < half_bandwidth <= 256 and enough unknowns (7m above ~900 for a
+ * band up to 128, above ~3100 up to 256) the same reduction runs on superblocks of 128 or 256
+ * unknowns, d_S again only read; anything else takes the general path of sfm_ba_solve_reduced
+ * (d_S destroyed).  Entries outside the stated band are never read on the band paths. */
 int sfm_ba_solve_reduced_banded(double* d_S, int32_t n7, int32_t half_bandwidth, double* d_delta_a,
                                 void* d_chol_ws, int32_t* d_info, void* stream);
 
@@ -332,6 +334,14 @@ int sfm_ba_update_cameras_prepare(double* d_R, double* d_T, double* d_C, double*
                                   int k_stride, const double* d_delta_a, int32_t m, int32_t first_cam,
                                   double q_step, double c_step, int32_t* d_flags, double* d_cam_blk,
                                   int32_t* d_blk_flags, void* stream);
+/* The same for a caller that keeps the cameras in another order than the frames' (an order that
+ * narrows the band of S, see sfm_ba_solve_reduced_banded): every camera but held_cam is updated
+ * (held_cam = -1: all of them) - the frame the loop of src/bundle_adjustment.py:84 starts after
+ * need not sit at index 0.  d_cam_blk / d_blk_flags may be NULL (no records prepared). */
+int sfm_ba_update_cameras_held(double* d_R, double* d_T, double* d_C, double* d_P, const double* d_K,
+                               int k_stride, const double* d_delta_a, int32_t m, int32_t held_cam,
+                               double q_step, double c_step, int32_t* d_flags, double* d_cam_blk,
+                               int32_t* d_blk_flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Cost.  Work of `compute_reprojection_error_total` (src/bundle_adjustment.py:9-19): per camera

@@ -1,4 +1,5 @@
-"""Time of the reduced solve for bands wider than 64 (general path): python scripts/probes/wide_band.py"""
+"""Time of the reduced solve for bands wider than 64: python scripts/probes/wide_band.py
+(SFM_BA_WIDE_BAND=0 in the environment: the general path instead of the reduction on superblocks.)"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -7,7 +8,11 @@ import sfm_amd
 from sfm_amd import synthetic, _lib
 from sfm_amd.device import DeviceProblem
 
-for m, n, k in ((500, 100_000, 12), (500, 100_000, 30), (1800, 300_000, 12), (1800, 300_000, 30)):
+CASES = ((500, 100_000, 12), (500, 100_000, 18), (500, 100_000, 30), (500, 50_000, 60), (1800, 300_000, 12),
+         (1800, 300_000, 18), (1800, 100_000, 30), (1800, 50_000, 60))
+if len(sys.argv) > 1:
+    CASES = [CASES[int(a)] for a in sys.argv[1:]]
+for m, n, k in CASES:
     p = synthetic.make_problem(m, n, k, visibility="banded", seed=0)
     prob = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true)
     prob.camera_prepare(); prob.jacobian(want_B=False)

@@ -69,6 +69,8 @@ SYMBOLS = {
     "sfm_ba_cost_partial": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_ba_update_cameras_prepare": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _i32, _i32, _f64, _f64, _vp, _vp, _vp,
                                              _vp]),
+    "sfm_ba_update_cameras_held": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _vp, _i32, _i32, _f64, _f64, _vp, _vp, _vp,
+                                             _vp]),
     "sfm_ba_cost": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_ba_cost_finish": (_int, [_vp, _i32, _vp, _vp]),
     "sfm_ba_cost_noalloc": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

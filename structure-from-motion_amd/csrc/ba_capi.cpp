@@ -209,7 +209,7 @@ int sfm_ba_update_cameras(double* d_R, double* d_T, double* d_C, double* d_P, co
                           int32_t* d_flags, void* stream) {
   if (!d_R || !d_T || !d_C || !d_K || !d_delta_a || m < 0 || first_cam < 0 || (k_stride != 0 && k_stride != 9))
     return SFM_BA_EINVAL;
-  return launch_update_cameras(d_R, d_T, d_C, d_P, d_K, k_stride, d_delta_a, m, first_cam, q_step, c_step, d_flags,
+  return launch_update_cameras(d_R, d_T, d_C, d_P, d_K, k_stride, d_delta_a, m, first_cam, -1, q_step, c_step, d_flags,
                                nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -219,7 +219,17 @@ int sfm_ba_update_cameras_prepare(double* d_R, double* d_T, double* d_C, double*
   if (!d_R || !d_T || !d_C || !d_K || !d_delta_a || !d_cam_blk || m < 0 || first_cam < 0 ||
       (k_stride != 0 && k_stride != 9))
     return SFM_BA_EINVAL;
-  return launch_update_cameras(d_R, d_T, d_C, d_P, d_K, k_stride, d_delta_a, m, first_cam, q_step, c_step, d_flags,
+  return launch_update_cameras(d_R, d_T, d_C, d_P, d_K, k_stride, d_delta_a, m, first_cam, -1, q_step, c_step, d_flags,
+                               d_cam_blk, d_blk_flags, static_cast<hipStream_t>(stream));
+}
+
+int sfm_ba_update_cameras_held(double* d_R, double* d_T, double* d_C, double* d_P, const double* d_K, int k_stride,
+                               const double* d_delta_a, int32_t m, int32_t held_cam, double q_step, double c_step,
+                               int32_t* d_flags, double* d_cam_blk, int32_t* d_blk_flags, void* stream) {
+  if (!d_R || !d_T || !d_C || !d_K || !d_delta_a || m < 0 || held_cam < -1 || held_cam >= m ||
+      (k_stride != 0 && k_stride != 9))
+    return SFM_BA_EINVAL;
+  return launch_update_cameras(d_R, d_T, d_C, d_P, d_K, k_stride, d_delta_a, m, 0, held_cam, q_step, c_step, d_flags,
                                d_cam_blk, d_blk_flags, static_cast<hipStream_t>(stream));
 }
 

@@ -50,13 +50,21 @@ __device__ long long g_stamps[48];
 // right-hand side of the substitutions), then either one int per (panel, row tile below it) - 1 when
 // that 64 x 64 tile of the factor is entirely zero (general path) - or [n_panels][NB*NB]
 // sub-diagonal factor tiles (band path)
+int wide_band_tiles(int n, int half_bandwidth);
+int64_t wide_workspace_doubles(int n, int C);
+
 int64_t cholesky_workspace_bytes(int n) {
   const int64_t np = (n + NB - 1) / NB;
+  // widest superblock the wide-band reduction may pick for this n (it wants four superblocks)
+  int64_t wide = 0;
+  for (int C = 2; C <= 4; C *= 2)
+    if (wide_band_tiles(n, NB * C) == C) wide = wide_workspace_doubles(n, C) * (int64_t)sizeof(double);
   const int64_t flags = (np * (np + 2) + 64) * (int64_t)sizeof(int32_t);
   const int64_t tiles = np * NB * NB * (int64_t)sizeof(double);
   const int64_t general = (np * NB * NB + np * NB + 64) * (int64_t)sizeof(double) + (flags > tiles ? flags : tiles);
   const int64_t reduction = (4 * np * NB * NB + np * NB + 64) * (int64_t)sizeof(double);  // D, B, P_u, P_d, e per block
-  return general > reduction ? general : reduction;
+  const int64_t narrow = general > reduction ? general : reduction;
+  return narrow > wide ? narrow : wide;
 }
 
 // value of `v` in lane `lane` (wave-uniform lane index)
@@ -1314,6 +1322,18 @@ int launch_solve_band_packed(double* packed, int n, double mu_diag, double* da, 
   return SFM_BA_OK;
 }
 
+#include "ba_bcr_wide.inc"
+
+// SFM_BA_WIDE_BAND=0 sends bands wider than 64 to the general factorisation (comparison runs);
+// SFM_BA_WIDE_BAND=<tiles> caps the superblock edge at that many tiles.
+static int wide_band_limit() {
+  static const int v = [] {
+    const char* e = getenv("SFM_BA_WIDE_BAND");
+    return e ? atoi(e) : kWideMaxTiles;
+  }();
+  return v;
+}
+
 __global__ void k_copy_row(const double* __restrict__ src, double* __restrict__ dst, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i];
@@ -1343,6 +1363,10 @@ int launch_solve_reduced(double* S, int n, int half_bandwidth, double* da, void*
       return SFM_BA_EHIP;
     }
     return SFM_BA_OK;
+  }
+  if (half_bandwidth > NB) {
+    const int Cw = wide_band_tiles(n, half_bandwidth);
+    if (Cw > 0 && Cw <= wide_band_limit()) return launch_solve_wide_band(S, n, Cw, da, ws, info, st);
   }
   for (int k = 0; k < np; ++k) {
     const int k0 = k * NB;

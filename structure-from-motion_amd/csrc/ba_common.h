@@ -193,7 +193,7 @@ int launch_back_substitute(const sfm_ba_plan* p, const double* A, const double* 
                            const double* Vinv, const double* eps_b, const double* da, double* db,
                            double* Xupd, double x_step, hipStream_t st);
 int launch_update_cameras(double* R, double* T, double* C, double* P, const double* K, int k_stride,
-                          const double* da, int m, int first, double q_step, double c_step,
+                          const double* da, int m, int first, int held, double q_step, double c_step,
                           int32_t* flags, double* blk, int32_t* blk_flags, hipStream_t st);
 int launch_cost(const sfm_ba_plan* p, const double* P, const double* X, const int32_t* cam, const int32_t* pt,
                 const double* xt, double* ssq, double* cost, void* ws, hipStream_t st);

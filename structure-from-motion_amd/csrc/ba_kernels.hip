@@ -1215,7 +1215,7 @@ __global__ __launch_bounds__(256) void k_back_substitute(
 // ------------------------------------------------------------------------------------------
 __global__ void k_update_cameras(double* __restrict__ R, double* __restrict__ T, double* __restrict__ C,
                                  double* __restrict__ P, const double* __restrict__ K, int k_stride,
-                                 const double* __restrict__ da, int m, int first, double q_step,
+                                 const double* __restrict__ da, int m, int first, int held, double q_step,
                                  double c_step, int32_t* __restrict__ flags, double* __restrict__ blk,
                                  int32_t* __restrict__ blk_flags) {
   // blk (may be null): the prepared record of every camera in its new state, what k_camera_prepare
@@ -1225,7 +1225,7 @@ __global__ void k_update_cameras(double* __restrict__ R, double* __restrict__ T,
   double r[9], q[4];
 #pragma unroll
   for (int i = 0; i < 9; ++i) r[i] = R[9 * (int64_t)j + i];
-  if (j < first) {
+  if (j < first || j == held) {  // cameras the loop holds: state kept, record still prepared
     if (blk) {
       double cc[3];
 #pragma unroll
@@ -1544,13 +1544,13 @@ int launch_back_substitute(const sfm_ba_plan* p, const double* A, const double* 
 }
 
 int launch_update_cameras(double* R, double* T, double* C, double* P, const double* K, int k_stride,
-                          const double* da, int m, int first, double q_step, double c_step,
+                          const double* da, int m, int first, int held, double q_step, double c_step,
                           int32_t* flags, double* blk, int32_t* blk_flags, hipStream_t st) {
   if (m <= 0) return SFM_BA_OK;
   {
     ProfScope ps(KID_UPDATE, st);
     hipLaunchKernelGGL(k_update_cameras, dim3((m + 63) / 64), dim3(64), 0, st, R, T, C, P, K, k_stride, da, m,
-                     first, q_step, c_step, flags, blk, blk_flags);
+                     first, held, q_step, c_step, flags, blk, blk_flags);
   }
   return check_launch("k_update_cameras");
 }

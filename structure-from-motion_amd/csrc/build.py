@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["ba_kernels.hip", "ba_fused.hip", "ba_cholesky.hip", "ba_triangulate.hip", "ba_pnp.hip", "ba_plan.cpp", "ba_plan_device.hip", "ba_capi.cpp", "ba_profile.cpp"]
-HEADERS = ["ba_common.h", "ba_fused_step_a.inc", "ba_fused_step_b.inc", "ba_fused_flush.inc",
+HEADERS = ["ba_common.h", "ba_bcr_wide.inc", "ba_fused_step_a.inc", "ba_fused_step_b.inc", "ba_fused_flush.inc",
            os.path.join("..", "..", "include", "sfm_ba.h")]
 LIB = os.path.join(HERE, "libsfm_ba.so")
 

@@ -125,8 +125,15 @@ class DeviceProblem:
     X_STEP = 0.5   # :100
 
     def __init__(self, K, R, T, X, cam_idx, pt_idx, x_true, n_cams=None, group=None, check=True, device=None,
-                 sharded=None, plan_where="device", steps=False, state=None):
+                 sharded=None, plan_where="device", steps=False, state=None, reorder=False):
         self.lib = _lib.load()
+        # reorder: when S is not a narrow band in the order given, look for a camera order in which
+        # it is narrower (ordering.narrowest_order: a sequence that closes a loop) and keep the cameras
+        # in that order on the device.  cameras() / set_state() translate; S, delta_a and everything
+        # per observation are then in the device's order (cam_order[i] = caller's index of camera i).
+        self.cam_order = None
+        self.cam_pos = None
+        self.natural_half_bandwidth = None
         self.device = _dev(device)
         # steps: keep the rows of A as step blocks (plans with runs only).  The assembly kernel then
         # reads whole contiguous KiB, but the blocks carry the empty (point, camera slot) lanes along,
@@ -153,6 +160,23 @@ class DeviceProblem:
         cam_idx = np.ascontiguousarray(cam_idx, dtype=np.int32)
         pt_idx = np.ascontiguousarray(pt_idx, dtype=np.int32)
         self.N = int(cam_idx.shape[0])
+        K = np.asarray(K, dtype=np.float64)
+        T = np.asarray(T, dtype=np.float64).reshape(-1, 3)
+        x_true = np.ascontiguousarray(x_true, dtype=np.float64).reshape(-1, 2)
+        if reorder and group is None and self.N > 0:
+            from . import ordering
+
+            hb_nat = ordering.half_bandwidth(np.arange(self.m), cam_idx, pt_idx, self.n)
+            self.natural_half_bandwidth = hb_nat
+            if hb_nat > 64:
+                hb_new, pos, order = ordering.narrowest_order(cam_idx, pt_idx, self.m, self.n, hb_nat)
+                # worth it when the new band reaches one of the band solvers
+                if pos is not None and hb_new <= 256 and 2 * hb_new <= hb_nat:
+                    cam_idx, pt_idx, x_true, _ = ordering.reorder_observations(pos, cam_idx, pt_idx, x_true)
+                    R, T = R[order], T[order]
+                    if K.ndim == 3:
+                        K = K[order]
+                    self.cam_order, self.cam_pos = order, pos
         sharded = self.sharded
         hinted = sharded or not check
         with torch.cuda.device(self.device):
@@ -177,7 +201,6 @@ class DeviceProblem:
             dist.all_reduce(hb, op=dist.ReduceOp.MAX, group=group)
             self.half_bandwidth = int(hb.item())
         d = self.device
-        K = np.asarray(K, dtype=np.float64)
         if K.ndim == 2:
             self.K = torch.from_numpy(K.reshape(1, 9).copy()).to(d)
             self.k_stride = 0
@@ -186,7 +209,6 @@ class DeviceProblem:
             self.k_stride = 9
             assert self.K.shape[0] == self.m
         self.R = torch.from_numpy(R.reshape(-1, 9).copy()).to(d)
-        T = np.asarray(T, dtype=np.float64).reshape(-1, 3)
         self.T = torch.from_numpy(T.copy()).to(d)
         Cc = -np.einsum("mji,mj->mi", R, T)
         self.C = torch.from_numpy(Cc).to(d)
@@ -212,10 +234,11 @@ class DeviceProblem:
     # -- state that the reference keeps on frames / map ---------------------------------------
     def set_state(self, C=None, P=None):
         """Override the derived camera centre / projection (frames may carry their own)."""
+        o = slice(None) if self.cam_order is None else self.cam_order
         if C is not None:
-            self.C.copy_(torch.from_numpy(np.asarray(C, dtype=np.float64).reshape(-1, 3)))
+            self.C.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(C, dtype=np.float64).reshape(-1, 3)[o])))
         if P is not None:
-            self.P.copy_(torch.from_numpy(np.asarray(P, dtype=np.float64).reshape(-1, 12)))
+            self.P.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(P, dtype=np.float64).reshape(-1, 12)[o])))
         self._blk_fresh = False
 
     def _alloc(self):
@@ -385,6 +408,14 @@ class DeviceProblem:
         """``prepare_next``: also leave the prepared camera records of the new state in ``cam_blk``
         (what ``camera_prepare`` would compute), so that the next iteration skips that launch."""
         p = _lib.ptr
+        if self.cam_pos is not None:
+            # the camera the loop holds is the caller's camera 0, wherever the device order put it
+            _lib.check(self.lib.sfm_ba_update_cameras_held(
+                p(self.R), p(self.T), p(self.C), p(self.P), p(self.K), self.k_stride, p(self.delta_a), self.m,
+                int(self.cam_pos[0]), float(self.Q_STEP), float(self.C_STEP), p(self.upd_flags),
+                p(self.cam_blk) if prepare_next else None, p(self.flags) if prepare_next else None, _stream()))
+            self._blk_fresh = bool(prepare_next)
+            return
         if prepare_next:
             _lib.check(self.lib.sfm_ba_update_cameras_prepare(
                 p(self.R), p(self.T), p(self.C), p(self.P), p(self.K), self.k_stride, p(self.delta_a), self.m, 1,
@@ -488,10 +519,13 @@ class DeviceProblem:
 
     # -- results back to the host --------------------------------------------------------------
     def cameras(self):
+        """(R, T, C, P) of every camera, in the caller's camera order."""
         R = self.R.cpu().numpy().reshape(-1, 3, 3)
         T = self.T.cpu().numpy().reshape(-1, 3)
         Cc = self.C.cpu().numpy().reshape(-1, 3)
         P = self.P.cpu().numpy().reshape(-1, 3, 4)
+        if self.cam_pos is not None:
+            R, T, Cc, P = R[self.cam_pos], T[self.cam_pos], Cc[self.cam_pos], P[self.cam_pos]
         return R, T, Cc, P
 
     def points(self):

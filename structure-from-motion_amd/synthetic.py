@@ -72,7 +72,15 @@ def _views(rng, m: int, n: int, k, visibility: str) -> tuple[np.ndarray, np.ndar
     kmax = int(kk.max())
     if kmax > m:
         raise ValueError("views per point exceeds number of cameras")
-    if visibility in ("banded", "closures"):
+    if visibility == "loop":
+        # one lap that ends where it started: k consecutive cameras on a ring, the last cameras
+        # see the points of the first ones.  In acquisition order S has blocks in its far corners;
+        # ordered along the folded ring it is a band twice as wide as the open sequence's.
+        if m < 4 * kmax:
+            raise ValueError("a loop needs at least four times as many cameras as views per point")
+        start = np.sort(rng.integers(0, m, size=n), kind="stable")
+        cams = (start[:, None] + np.arange(kmax)[None, :]) % m
+    elif visibility in ("banded", "closures"):
         # k consecutive cameras from a random start (no wrap-around: S is block-banded).  Point
         # ids ascend with the first observing camera, as they do in the incremental pipeline
         # that feeds the reference's BA: new points are appended to the map when a frame is
@@ -83,17 +91,19 @@ def _views(rng, m: int, n: int, k, visibility: str) -> tuple[np.ndarray, np.ndar
         offs = np.arange(kmax)[None, :]
         cams = start[:, None] + offs
         if visibility == "closures":
-            # a sequence that comes back to places it has seen: one point in a thousand keeps the
-            # first half of its views and takes the other half from cameras half a sequence away,
+            # two laps over the same places: one point in a thousand keeps the
+            # first half of its views and takes the other half from cameras half a sequence later,
             # so S gains blocks far from the diagonal and is no longer block-tridiagonal
             if m < 4 * kmax:
                 raise ValueError("closures need at least four times as many cameras as views per point")
+            # (drawn among the points of the first half of the sequence, whose cameras have a
+            # counterpart m // 2 further on: the second pass sees what the first pass saw)
+            early = np.flatnonzero(start + m // 2 + kmax <= m)
             far = np.zeros(n, dtype=bool)
-            far[rng.choice(n, size=max(1, n // 1000), replace=False)] = True
+            far[rng.choice(early, size=max(1, n // 1000), replace=False)] = True
             half = (kk + 1) // 2
-            jump = (start + m // 2) % (m - kmax + 1) - start
             moved = far[:, None] & (offs >= half[:, None])
-            cams = np.where(moved, cams + jump[:, None], cams)
+            cams = np.where(moved, cams + m // 2, cams)
     elif visibility == "uniform":
         # random k-subset of the m cameras per point: draw k cameras, redraw the
         # rows that hold a duplicate until none is left (k << m in every workload)

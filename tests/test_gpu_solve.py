@@ -1,5 +1,6 @@
-"""GPU tests of the reduced camera solve through the C ABI: the three paths (general blocked
-Cholesky, single-workgroup band chain, block cyclic reduction) against numpy on the same system.
+"""GPU tests of the reduced camera solve through the C ABI: the paths (general blocked Cholesky,
+single-workgroup band chain, block cyclic reduction on 64-blocks and on superblocks for wider
+bands) against numpy on the same system.
 
 The reference solves S delta_a = e with numpy.linalg.solve (src/sparse_ba.py:274-276); the
 systems here are well conditioned, so every path must agree with it to ~1e-13.
@@ -63,6 +64,24 @@ def test_banded_paths_match_numpy(n, hb):
     assert np.linalg.norm(x2 - x_ref) <= 1e-12 * np.linalg.norm(x_ref)
 
 
+# bands wider than one 64-block: cyclic reduction on superblocks of 2 or 4 tiles (128, 256 unknowns)
+# with 9, 9 (partial last one), 33 and 14, 13 superblocks; (600, 100), (1300, 200) and (2500, 300) have
+# too few superblocks or too wide a band for it and go through the general path
+WIDE_CASES = [(1100, 128), (1030, 70), (4200, 65), (3400, 130), (3300, 200), (600, 100), (1300, 200), (2500, 300)]
+
+
+@pytest.mark.parametrize("n,hb", WIDE_CASES)
+def test_wide_band_reduction_matches_numpy(n, hb):
+    S, e = _system(n, hb, seed=n)
+    x_ref = np.linalg.solve(S, e)
+    x, info, S_after = _solve(S, e, hb, banded_entry=True)
+    assert info == 0
+    assert np.linalg.norm(x - x_ref) <= 1e-12 * np.linalg.norm(x_ref)
+    # the reduction only reads the matrix; the general path factors it in place
+    on_superblocks = (hb <= 128 and -(-n // 128) >= 8) or (128 < hb <= 256 and -(-n // 256) >= 13)
+    assert np.array_equal(S_after, S) == on_superblocks
+
+
 def test_wide_band_takes_general_path():
     S, e = _system(400, 150, seed=3)
     x_ref = np.linalg.solve(S, e)
@@ -71,7 +90,8 @@ def test_wide_band_takes_general_path():
     assert np.linalg.norm(x - x_ref) <= 1e-12 * np.linalg.norm(x_ref)
 
 
-@pytest.mark.parametrize("n,hb,bad_row", [(100, 48, 70), (640, 48, 200), (640, 48, 0), (640, None, 333)])
+@pytest.mark.parametrize("n,hb,bad_row", [(100, 48, 70), (640, 48, 200), (640, 48, 0), (640, None, 333), (1100, 100, 500),
+                                           (1100, 100, 1099)])
 def test_not_positive_definite_is_reported(n, hb, bad_row):
     """A non-positive pivot is what numpy's LU would not notice but a Cholesky must: the library
     reports 1 + the index of a failing pivot (status SFM_BA_ENOTPD at the Python layer)."""
