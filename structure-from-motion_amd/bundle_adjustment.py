@@ -40,10 +40,11 @@ def _flatten(frames):
     return vi, np.concatenate(pi), np.vstack(xt)
 
 
-def _problem_from(frames, map_, check=True):
+def _problem_from(frames, map_, check=True, reorder=False):
     K, R, T, C, P = _pack_frames(frames)
     vi, pi, x_t = _flatten(frames)
-    prob = DeviceProblem(K, R, T, np.asarray(map_.X)[:, :3], vi, pi, x_t, n_cams=len(frames), check=check)
+    prob = DeviceProblem(K, R, T, np.asarray(map_.X)[:, :3], vi, pi, x_t, n_cams=len(frames), check=check,
+                         reorder=reorder)
     prob.set_state(C=C, P=P)
     return prob, vi, pi, x_t
 
@@ -71,12 +72,14 @@ def compute_A_B(frames, map_, viewpoints_indices, point_indices):
     return A, B
 
 
-def optimize_using_BA(frames, map_, verbose=True, max_iter=50, threshold=100.0):
+def optimize_using_BA(frames, map_, verbose=True, max_iter=50, threshold=100.0, reorder=False):
     """Iterate damped Gauss-Newton steps (mu = 0.5) while the cost exceeds ``threshold`` and
     fewer than ``max_iter`` iterations ran; updates ``frame.R/T/C/RT/P`` of every frame but
     the first and ``map_.X[:, :3]`` in place.  Returns the per-iteration costs (the
-    reference returns None and prints them)."""
-    prob, vi, pi, _ = _problem_from(frames, map_, check=True)
+    reference returns None and prints them).  ``reorder`` (not in the reference): for sequences
+    that revisit places, solve with the cameras in the order that narrows the band of the reduced
+    system (``sfm_amd.ordering``); results are the same to rounding and come back per frame."""
+    prob, vi, pi, _ = _problem_from(frames, map_, check=True, reorder=reorder)
     # check_args of the step (src/sparse_ba.py:39-46)
     if not can_run_ba(prob.m, prob.n, prob.N, 7, 3):
         raise ValueError("n_rows(J) must be greater than n_cols(J)")

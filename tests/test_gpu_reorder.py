@@ -94,3 +94,25 @@ def test_update_cameras_held_argument_checks():
         rc = lib.sfm_ba_update_cameras_held(p(z), p(z), p(z), None, p(z), 0, p(z), 4, held, 1.0, 0.1, p(f), None, None,
                                             None)
         assert rc == _lib.EINVAL
+
+
+def test_drop_in_entry_with_reorder():
+    """optimize_using_BA(frames, map_, reorder=True) on a closed loop: same frames and map as without."""
+    import copy
+
+    import sfm_amd  # noqa: F401
+    from sfm_amd import bundle_adjustment as ba
+    from sfm_amd import synthetic
+    from sfm_amd.frame import Frame, Map
+
+    p = synthetic.make_problem(40, 2500, 5, visibility="loop", seed=12)
+    frames_a, map_a = synthetic.to_frames_and_map(p, Frame, Map, extra_keypoints=3)
+    frames_b, map_b = copy.deepcopy(frames_a), copy.deepcopy(map_a)
+    ca = ba.optimize_using_BA(frames_a, map_a, verbose=False, max_iter=3, threshold=0.0)
+    cb = ba.optimize_using_BA(frames_b, map_b, verbose=False, max_iter=3, threshold=0.0, reorder=True)
+    assert np.max(np.abs(np.asarray(ca) - np.asarray(cb)) / np.asarray(ca)) < 1e-9
+    for fa, fb in zip(frames_a, frames_b):
+        assert np.max(np.abs(fa.R - fb.R)) < 1e-8 and np.max(np.abs(fa.T - fb.T)) < 1e-8
+        assert np.max(np.abs(fa.P - fb.P)) < 1e-8 * np.max(np.abs(fa.P))
+    assert np.array_equal(frames_b[0].R, p.R[0])
+    assert np.max(np.abs(map_a.X - map_b.X)) < 1e-8 * np.max(np.abs(map_a.X))
