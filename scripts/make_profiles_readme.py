@@ -22,6 +22,10 @@ rows = [("default", "c4_500x300k banded (the `bench.py` default)"),
         ("ladybug50_banded", "ladybug50 banded"), ("ladybug50_uniform", "ladybug50 uniform"),
         ("venice1800_banded", "venice1800 banded"),
         ("venice1800_banded_rows", "venice1800 banded, rows of A materialised (`SFM_BA_STATE=0`)"), ("venice1800_uniform", "venice1800 uniform (dense S, 12 600 unknowns)")]
+for w in ("c4_500x300k", "venice1800"):
+    for v, what in (("loop", "one lap closing a loop"), ("closures", "two laps over the same places")):
+        rows.append((f"{w}_{v}", f"{w} {what}, cameras in the folded order"))
+        rows.append((f"{w}_{v}_acquisition", f"{w} {what}, cameras in acquisition order (`SFM_BA_REORDER=0`)"))
 out = [f"# profiles — round {tag[1:]} evidence (MI355X, one GPU)", "",
        "Produced by `bash scripts/gpu_evidence.sh <tag>` on the GPU box; this file is generated from the files next to it",
        "by `scripts/make_profiles_readme.py`.", "",
@@ -40,8 +44,10 @@ for key, label in rows:
         stages = "(%.0f) / %.0f" % (g["jacobian+assembly"]["GBps"], g["back_substitution"]["GBps"])
     else:
         stages = "%.0f / %.0f / %.0f" % (g["jacobian"]["GBps"], g["assembly"]["GBps"], g["back_substitution"]["GBps"])
+    order = c.get("camera_order", "")
     out.append("| %s | %d x %d x %d | %s | %.3f / %.3f | %.3g | %.3f (%s) | %s |" % (
-        label, c["cameras"], c["points"], c["observations"], c.get("assembly", ""), d["ms_per_step"], d["ms_per_step_without_events"],
+        label, c["cameras"], c["points"], c["observations"],
+        c.get("assembly", "") + ("; " + order if order.startswith("folded") else ""), d["ms_per_step"], d["ms_per_step_without_events"],
         d["value"], d["solve"]["ms"], d["solve"].get("path", "blocked Cholesky"), stages))
 d = bench("default")
 if d is not None:
