@@ -353,7 +353,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-uniform-record", action="store_true",
-                    help="skip the short extra run of the same workload with uniform visibility")
+                    help="skip the short extra runs of the same workload with uniform visibility and as a closed loop")
     ap.add_argument("--triangulate", type=int, default=0, metavar="N",
                     help="benchmark the two-view triangulation kernel on N correspondences instead")
     ap.add_argument("--pnp", type=int, default=0, metavar="N",
@@ -570,6 +570,28 @@ def main():
                 "solve": solve_record(uprof, usteps, n7, up.half_bandwidth),
             }
             del up, u
+            torch.cuda.empty_cache()
+            # and as one lap that ends where it started (a closed loop): cameras kept in the folded order,
+            # camera-pair assembly, band solve
+            if m >= 4 * (k if isinstance(k, int) else k[1]):
+                lp = synthetic.make_workload(args.workload, visibility="loop", seed=args.seed, points=n_total)
+                lprob = DeviceProblem(lp.K, lp.R, lp.T, lp.X, lp.cam_idx, lp.pt_idx, lp.x_true, n_cams=m, check=True,
+                                      plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"), reorder=True)
+                ldt, lprof, _ = stage_times(lprob, usteps, 2, 1, barrier)
+                lprob.check_flags()
+                lb = 2 * lprob.plan.n_blocks - m
+                out["loop_visibility"] = {
+                    "workload": f"{args.workload}: {m} cameras x {lp.n} points x {lp.n_obs} observations, "
+                                "one lap closing a loop",
+                    "camera_order": ("acquisition order" if lprob.cam_order is None else
+                                     f"folded (half bandwidth {lprob.natural_half_bandwidth} in acquisition order, "
+                                     f"{lprob.half_bandwidth} on the device)"),
+                    "steps": usteps, "ms_per_step": ldt / usteps * 1e3, "value": lp.n_obs * usteps / ldt, "unit": "obs/s",
+                    "nonzero_S_blocks": lb,
+                    "groups": stage_groups(lprof, usteps, lprob.N, lprob.n, m, lb, {}),
+                    "solve": solve_record(lprof, usteps, n7, lprob.half_bandwidth),
+                }
+                del lprob, lp
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.visibility, args.seed)
         print(json.dumps(out))

@@ -170,8 +170,9 @@ class DeviceProblem:
             self.natural_half_bandwidth = hb_nat
             if hb_nat > 64:
                 hb_new, pos, order = ordering.narrowest_order(cam_idx, pt_idx, self.m, self.n, hb_nat)
-                # worth it when the new band reaches one of the band solvers
-                if pos is not None and hb_new <= 256 and 2 * hb_new <= hb_nat:
+                # worth it when the band halves: up to 256 it reaches a band solver, above that the
+                # general factorisation still skips the zero tiles outside it
+                if pos is not None and 2 * hb_new <= hb_nat:
                     cam_idx, pt_idx, x_true, _ = ordering.reorder_observations(pos, cam_idx, pt_idx, x_true)
                     R, T = R[order], T[order]
                     if K.ndim == 3:

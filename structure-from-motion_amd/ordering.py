@@ -71,8 +71,9 @@ def spectral_positions(cam_idx, pt_idx, n_cams: int, n_points: int):
     """(position of every camera, camera at every position) by the second eigenvector of the
     Laplacian of the co-visibility graph (unit weights): along a sequence that folds back on
     itself the eigenvector varies with the place, not with the time of acquisition, so sorting
-    by it interleaves the passes through the same place.  None when the graph is not connected
-    or the eigen-solver does not converge."""
+    by it interleaves the passes through the same place.  None when the graph is not connected,
+    when it is so dense that no order gives a band (more than 128 neighbours per camera on
+    average), or when the eigen-solver does not converge."""
     from scipy.sparse import csr_matrix, diags
     from scipy.sparse.csgraph import connected_components
     from scipy.sparse.linalg import eigsh
@@ -86,6 +87,8 @@ def spectral_positions(cam_idx, pt_idx, n_cams: int, n_points: int):
     G.data[:] = 1.0
     G.setdiag(0.0)
     G.eliminate_zeros()
+    if G.nnz > 128 * n_cams:
+        return None  # cameras share points with most other cameras: no band in any order
     if connected_components(G, directed=False, return_labels=False) != 1:
         return None
     deg = np.asarray(G.sum(axis=1)).reshape(-1)
