@@ -315,11 +315,9 @@ def stage_groups(prof, steps, N, n, m, s_blocks, pmc):
 
 def solve_record(prof, steps, n7, hb):
     solve_ms = prof.get("solve_reduced", (0.0, 1))[0] / steps
-    # superblock edge of the wide-band reduction (the library's rule: the band fits one superblock and
-    # there are enough superblocks for the rounds to beat the general path's panel chain)
-    wide = 128 if 64 < hb <= 128 and -(-n7 // 128) >= 8 else 256 if 128 < hb <= 256 and -(-n7 // 256) >= 13 else 0
-    if os.environ.get("SFM_BA_WIDE_BAND") == "0":
-        wide = 0
+    # edge of the blocks the library's band paths work on for this size and band (0: general path)
+    blk = int(_lib.load().sfm_ba_reduced_solve_block(int(n7), int(hb)))
+    wide = blk if blk > 64 else 0
     if hb <= 64:
         # band Cholesky + two band substitutions
         flops, path = n7 * (hb + 1.0) ** 2 + 4.0 * n7 * (hb + 1.0), "block cyclic reduction (band)"

@@ -276,9 +276,25 @@ int sfm_ba_solve_reduced(double* d_S, int32_t n7, double* d_delta_a, void* d_cho
  * and d_S is only read; with 64 < half_bandwidth <= 256 and enough unknowns (7m above ~900 for a
  * band up to 128, above ~3100 up to 256) the same reduction runs on superblocks of 128 or 256
  * unknowns, d_S again only read; anything else takes the general path of sfm_ba_solve_reduced
- * (d_S destroyed).  Entries outside the stated band are never read on the band paths. */
+ * (d_S destroyed).  The band paths read whole blocks - entries up to twice the block edge
+ * (sfm_ba_reduced_solve_block) below the diagonal, which must hold their zeros - and nothing beyond. */
 int sfm_ba_solve_reduced_banded(double* d_S, int32_t n7, int32_t half_bandwidth, double* d_delta_a,
                                 void* d_chol_ws, int32_t* d_info, void* stream);
+/* Which of those paths a size and band take: the edge of the blocks the solve works on - 64 (cyclic
+ * reduction / block chain), 128 or 256 (reduction on superblocks) - or 0 for the general
+ * factorisation.  No counterpart in the reference (numpy.linalg.solve has one path). */
+int32_t sfm_ba_reduced_solve_block(int32_t n7, int32_t half_bandwidth);
+/* The system of src/sparse_ba.py:274-276 with its cameras renumbered, for a caller that assembles in
+ * the frames' order and solves in an order with a narrower band: row / column 7 p + a of d_S_out is
+ * row / column 7 d_cam_order[p] + a of d_S (both [(n7+1) x n7], right-hand side in row n7; d_cam_order
+ * [n7 / 7] = the camera at position p).  Only the lower triangle of d_S is read; of d_S_out the
+ * lower-triangle entries within half_bandwidth of the diagonal and row n7 are written (pass n7 to
+ * get the whole lower triangle; for a band path pass 2 * sfm_ba_reduced_solve_block(...) - 1, what
+ * that path reads).  The solution of the renumbered system is delta_a in the new order:
+ * delta_a of camera d_cam_order[p] is its block p. */
+int sfm_ba_permute_system(const double* d_S, int32_t n7, const int32_t* d_cam_order, int32_t half_bandwidth,
+                          double* d_S_out, void* stream);
+
 
 /* Packed form of a narrow-band system (half bandwidth <= 64), for sharded runs: S is block
  * tridiagonal in 64 x 64 blocks, and [diagonal blocks | couplings | right-hand side] is all of it -

@@ -52,6 +52,8 @@ SYMBOLS = {
     "sfm_ba_cholesky_workspace_bytes": (_i64, [_i32]),
     "sfm_ba_solve_reduced": (_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "sfm_ba_solve_reduced_banded": (_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "sfm_ba_reduced_solve_block": (_i32, [_i32, _i32]),
+    "sfm_ba_permute_system": (_int, [_vp, _i32, _vp, _i32, _vp, _vp]),
     "sfm_ba_plan_half_bandwidth": (_i32, [_vp]),
     "sfm_ba_triangulate": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "sfm_ba_pnp_workspace_bytes": (_i64, [_i32, _i32]),

@@ -137,6 +137,17 @@ int sfm_ba_solve_reduced_banded(double* d_S, int32_t n7, int32_t half_bandwidth,
                               static_cast<hipStream_t>(stream));
 }
 
+int32_t sfm_ba_reduced_solve_block(int32_t n7, int32_t half_bandwidth) {
+  return n7 > 0 && half_bandwidth >= 0 ? reduced_solve_block(n7, half_bandwidth) : 0;
+}
+
+int sfm_ba_permute_system(const double* d_S, int32_t n7, const int32_t* d_cam_order, int32_t half_bandwidth,
+                          double* d_S_out, void* stream) {
+  if (!d_S || !d_cam_order || !d_S_out || d_S == d_S_out || n7 < 0 || n7 % 7 != 0 || half_bandwidth < 0)
+    return SFM_BA_EINVAL;
+  return launch_permute_system(d_S, n7, d_cam_order, half_bandwidth, d_S_out, static_cast<hipStream_t>(stream));
+}
+
 int sfm_ba_triangulate(const double* d_x1, const double* d_x2, const double* d_P1, const double* d_P2, int64_t n,
                        float* d_Xh, void* stream) {
   if (n < 0 || (n > 0 && (!d_x1 || !d_x2 || !d_P1 || !d_P2 || !d_Xh))) return SFM_BA_EINVAL;

@@ -1334,6 +1334,45 @@ static int wide_band_limit() {
   return v;
 }
 
+// Edge of the blocks the reduced solve works on for this size and band: 64 (cyclic reduction /
+// block chain), 128 or 256 (reduction on superblocks), 0 for the general factorisation.
+int reduced_solve_block(int n, int half_bandwidth) {
+  if (half_bandwidth >= 0 && half_bandwidth <= NB) return NB;
+  const int Cw = wide_band_tiles(n, half_bandwidth);
+  return Cw > 0 && Cw <= wide_band_limit() ? NB * Cw : 0;
+}
+
+// S with its cameras renumbered: row / column 7 p + a of `dst` is row / column 7 order[p] + a of `src`
+// (7 x 7 blocks move whole).  Only the lower triangle of src is read; of dst the entries with
+// r - c <= half_bandwidth of the lower triangle and the right-hand-side row are written.
+__global__ __launch_bounds__(256) void k_permute_system(const double* __restrict__ src, int n,
+                                                        const int32_t* __restrict__ order, int hb,
+                                                        double* __restrict__ dst) {
+  const int r = blockIdx.x;  // 0 .. n: row n is the right-hand side
+  if (r == n) {
+    for (int c = threadIdx.x; c < n; c += 256) dst[(int64_t)n * n + c] = src[(int64_t)n * n + 7 * order[c / 7] + c % 7];
+    return;
+  }
+  const int rs = 7 * order[r / 7] + r % 7;
+  const int c_lo = r - hb < 0 ? 0 : r - hb;
+  for (int c = c_lo + threadIdx.x; c <= r; c += 256) {
+    const int cs = 7 * order[c / 7] + c % 7;
+    dst[(int64_t)r * n + c] = rs >= cs ? src[(int64_t)rs * n + cs] : src[(int64_t)cs * n + rs];
+  }
+}
+
+int launch_permute_system(const double* src, int n, const int32_t* order, int half_bandwidth, double* dst,
+                          hipStream_t st) {
+  if (n <= 0) return SFM_BA_OK;
+  hipLaunchKernelGGL(k_permute_system, dim3(n + 1), dim3(256), 0, st, src, n, order, half_bandwidth, dst);
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    set_hip_error(err, "k_permute_system launch");
+    return SFM_BA_EHIP;
+  }
+  return SFM_BA_OK;
+}
+
 __global__ void k_copy_row(const double* __restrict__ src, double* __restrict__ dst, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i];

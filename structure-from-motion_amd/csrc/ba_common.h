@@ -205,6 +205,9 @@ int launch_cost_noalloc(const sfm_ba_plan* p, const double* P, const double* X, 
 int64_t cholesky_workspace_bytes(int n7);
 // half_bandwidth < 0: dense; otherwise S[r][c] = 0 wherever |r - c| > half_bandwidth
 int launch_solve_reduced(double* S, int n7, int half_bandwidth, double* da, void* ws, int32_t* info, hipStream_t st);
+int reduced_solve_block(int n7, int half_bandwidth);
+int launch_permute_system(const double* src, int n7, const int32_t* order, int half_bandwidth, double* dst,
+                          hipStream_t st);
 
 int64_t band_packed_elements(int n7);
 int launch_band_pack(const double* S, int n7, double* packed, hipStream_t st);
