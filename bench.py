@@ -291,10 +291,12 @@ def stage_groups(prof, steps, N, n, m, s_blocks, pmc):
     as a materialised array, counter traffic where a PMC pass of these kernels is on file."""
     alg, alg_b = algorithmic_bytes(N, n, m, s_blocks), algorithmic_bytes(N, n, m, s_blocks, with_B=True)
     stages = dict(GROUPS)
-    if "k_fused_state" in prof and "k_jacobian" not in prof:
+    if "k_fused_state" in prof:
         # the rows of A are formed inside the assembly kernel: one stage does the work of two, and is
-        # priced with the bytes of both (what the two stages would have to move between them)
-        stages = {"jacobian+assembly": GROUPS["assembly"], "back_substitution": GROUPS["back_substitution"]}
+        # priced with the bytes of both (what the two stages would have to move between them).  A split
+        # problem also runs the Jacobian and camera-pair kernels, over its few far points: same stage.
+        stages = {"jacobian+assembly": list(GROUPS["jacobian"]) + list(GROUPS["assembly"]),
+                  "back_substitution": GROUPS["back_substitution"]}
         for d in (alg, alg_b):
             d["jacobian+assembly"] = d["jacobian"] + d["assembly"]
     groups = {}
@@ -315,6 +317,8 @@ def stage_groups(prof, steps, N, n, m, s_blocks, pmc):
 
 def solve_record(prof, steps, n7, hb):
     solve_ms = prof.get("solve_reduced", (0.0, 1))[0] / steps
+    from sfm_amd import _lib
+
     # edge of the blocks the library's band paths work on for this size and band (0: general path)
     blk = int(_lib.load().sfm_ba_reduced_solve_block(int(n7), int(hb)))
     wide = blk if blk > 64 else 0
@@ -396,6 +400,7 @@ def main():
     import sfm_amd  # noqa: F401
     from sfm_amd import _lib, synthetic
     from sfm_amd.device import DeviceProblem
+    from sfm_amd.split import SplitProblem
     from sfm_amd.dist import local_problem, packed_system_elements
 
     if os.environ.get("SFM_BA_BENCH_WATCHDOG"):
@@ -430,13 +435,26 @@ def main():
     else:
         prob_h = full
     del full
-    prob = DeviceProblem(prob_h.K, prob_h.R, prob_h.T, prob_h.X, prob_h.cam_idx, prob_h.pt_idx, prob_h.x_true,
-                         n_cams=m, group=group, check=(world == 1),
-                         plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"),
-                         steps=bool(int(os.environ.get("SFM_BA_STEPS", "0"))),
-                         # sequences that revisit places: cameras in the folded order (one GPU only)
-                         reorder=(world == 1 and args.visibility in ("loop", "closures")
-                                  and os.environ.get("SFM_BA_REORDER", "1") != "0"))
+    revisits = world == 1 and args.visibility in ("loop", "closures") and os.environ.get("SFM_BA_REORDER", "1") != "0"
+    prob = None
+    if revisits and os.environ.get("SFM_BA_SPLIT", "1") != "0":
+        # sequences that revisit places: near points through the fused assembly, far points through the
+        # camera-pair kernels, band solve in the folded camera order
+        try:
+            prob = SplitProblem(prob_h.K, prob_h.R, prob_h.T, prob_h.X, prob_h.cam_idx, prob_h.pt_idx, prob_h.x_true,
+                                n_cams=m, plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"))
+        except ValueError:
+            prob = None
+    if prob is None:
+        # (for revisits with the split refused or switched off: all cameras in the folded order,
+        # camera-pair assembly)
+        prob = DeviceProblem(prob_h.K, prob_h.R, prob_h.T, prob_h.X, prob_h.cam_idx, prob_h.pt_idx, prob_h.x_true,
+                             n_cams=m, group=group, check=(world == 1),
+                             plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"),
+                             steps=bool(int(os.environ.get("SFM_BA_STEPS", "0"))), reorder=revisits)
+    is_split = isinstance(prob, SplitProblem)
+    fused_plan = prob.near.plan if is_split else prob.plan  # the plan whose runs the fused kernels walk
+    n_blocks = prob.n_blocks if is_split else prob.plan.n_blocks
     N_loc, n_loc = prob.N, prob.n
 
     def barrier():
@@ -472,7 +490,7 @@ def main():
 
     if rank == 0:
         per_kernel = {name: {"ms_avg": ms / cnt, "launches_per_step": cnt / args.steps} for name, (ms, cnt) in prof.items()}
-        s_blocks = 2 * prob.plan.n_blocks - m  # plan counts pairs j <= k
+        s_blocks = 2 * n_blocks - m  # plan counts pairs j <= k
         pmc = measured_traffic(args.workload, args.visibility) if world == 1 else {}
         groups = stage_groups(prof, args.steps, N_loc, n_loc, m, s_blocks, pmc)
         # the dominant HBM-bound stage; its algorithmic bytes are defined per stage, so a stage that
@@ -499,13 +517,13 @@ def main():
                     "real traffic (the traffic field) is far smaller, because A never goes to memory, and what "
                     "bounds it is the fp64 pipe, not HBM",
         }
-        if prob.plan.fused and ("k_fused_state" in prof or "k_fused_runs" in prof):
+        if fused_plan.fused and ("k_fused_state" in prof or "k_fused_runs" in prof):
             # the fused kernel is bound by the fp64 pipe (matrix and vector instructions share it), not by
             # HBM: matrix-instruction flops it executes per launch, exactly, against the fp64 peak
             kn = "k_fused_state" if "k_fused_state" in prof else "k_fused_runs"
-            slots = prob.plan.fused_slots
+            slots = fused_plan.fused_slots
             tiles = 2 if slots <= 4 else (3 if slots <= 7 else 4)
-            mfma_flops = prob.plan.n_steps * (tiles * (tiles + 1) // 2) * 6 * 2048.0
+            mfma_flops = fused_plan.n_steps * (tiles * (tiles + 1) // 2) * 6 * 2048.0
             t = prof[kn][0] / prof[kn][1] * 1e-3
             roofline["fp64_pipe"] = {
                 "kernel": kn, "matrix_flops": mfma_flops, "achieved": mfma_flops / t / 1e12, "peak": FP64_PEAK_TFLOPS,
@@ -538,8 +556,11 @@ def main():
                 "nonzero_S_blocks": s_blocks,
                 "camera_order": ("acquisition order" if prob.cam_order is None else
                                  f"folded (half bandwidth {prob.natural_half_bandwidth} in acquisition order, "
-                                 f"{prob.half_bandwidth} on the device)"),
-                "assembly": ("fused point-major, rows of A formed in the kernel" if prob.from_state and prob.plan.fused
+                                 f"{prob.half_bandwidth} folded"
+                                 + ("; only the solve sees the folded order)" if is_split else "; on the device)")),
+                "assembly": (f"split: fused point-major with the rows of A formed in the kernel for {prob.near.n} near "
+                             f"points, camera-pair for {prob.far.n} far points" if is_split
+                             else "fused point-major, rows of A formed in the kernel" if prob.from_state and prob.plan.fused
                              else "fused point-major" if prob.plan.fused else "camera-pair"),
                 "parallelism": "1 gpu" if world == 1 else f"point-id sharding x{world}, all-reduce of "
                                f"{packed_system_elements(m, prob.half_bandwidth) * 8 / 1e6:.1f} MB per iteration",
@@ -573,17 +594,25 @@ def main():
             # camera-pair assembly, band solve
             if m >= 4 * (k if isinstance(k, int) else k[1]):
                 lp = synthetic.make_workload(args.workload, visibility="loop", seed=args.seed, points=n_total)
-                lprob = DeviceProblem(lp.K, lp.R, lp.T, lp.X, lp.cam_idx, lp.pt_idx, lp.x_true, n_cams=m, check=True,
-                                      plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"), reorder=True)
+                try:
+                    lprob = SplitProblem(lp.K, lp.R, lp.T, lp.X, lp.cam_idx, lp.pt_idx, lp.x_true, n_cams=m,
+                                         plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"))
+                except ValueError:
+                    lprob = DeviceProblem(lp.K, lp.R, lp.T, lp.X, lp.cam_idx, lp.pt_idx, lp.x_true, n_cams=m, check=True,
+                                          plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"), reorder=True)
                 ldt, lprof, _ = stage_times(lprob, usteps, 2, 1, barrier)
                 lprob.check_flags()
-                lb = 2 * lprob.plan.n_blocks - m
+                lsplit = isinstance(lprob, SplitProblem)
+                lb = 2 * (lprob.n_blocks if lsplit else lprob.plan.n_blocks) - m
                 out["loop_visibility"] = {
                     "workload": f"{args.workload}: {m} cameras x {lp.n} points x {lp.n_obs} observations, "
                                 "one lap closing a loop",
                     "camera_order": ("acquisition order" if lprob.cam_order is None else
                                      f"folded (half bandwidth {lprob.natural_half_bandwidth} in acquisition order, "
-                                     f"{lprob.half_bandwidth} on the device)"),
+                                     f"{lprob.half_bandwidth} folded)"),
+                    "assembly": (f"split: fused point-major for {lprob.near.n} near points, camera-pair for "
+                                 f"{lprob.far.n} far points, system renumbered for the solve" if lsplit
+                                 else "camera-pair, cameras kept in the folded order"),
                     "steps": usteps, "ms_per_step": ldt / usteps * 1e3, "value": lp.n_obs * usteps / ldt, "unit": "obs/s",
                     "nonzero_S_blocks": lb,
                     "groups": stage_groups(lprof, usteps, lprob.N, lprob.n, m, lb, {}),

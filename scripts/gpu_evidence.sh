@@ -29,11 +29,13 @@ for W in "ladybug50 banded" "ladybug50 uniform" "c4_500x300k uniform" "venice180
   set -- $W
   timeout -k 10 500 python3 bench.py --workload $1 --visibility $2 --no-cpu-baseline --no-uniform-record > gpurun_out/${TAG}_bench_$1_$2.json 2> gpurun_out/${TAG}_bench_$1_$2.err || exit 5
 done
-# sequences that revisit places (one lap closing a loop; two laps): cameras in the folded order, and
-# the same problems in acquisition order
+# sequences that revisit places (one lap closing a loop; two laps): split (near points fused in acquisition
+# order, far points camera-pair, solve in the folded order), everything in the folded order, and the
+# same problems in acquisition order
 for W in "c4_500x300k loop" "venice1800 loop" "c4_500x300k closures" "venice1800 closures"; do
   set -- $W
   timeout -k 10 500 python3 bench.py --workload $1 --visibility $2 --no-cpu-baseline --no-uniform-record > gpurun_out/${TAG}_bench_$1_$2.json 2> gpurun_out/${TAG}_bench_$1_$2.err || exit 5
+  SFM_BA_SPLIT=0 timeout -k 10 500 python3 bench.py --workload $1 --visibility $2 --no-cpu-baseline --no-uniform-record > gpurun_out/${TAG}_bench_$1_$2_folded.json 2> gpurun_out/${TAG}_bench_$1_$2_folded.err || exit 5
   SFM_BA_REORDER=0 timeout -k 10 500 python3 bench.py --workload $1 --visibility $2 --no-cpu-baseline --no-uniform-record > gpurun_out/${TAG}_bench_$1_$2_acquisition.json 2> gpurun_out/${TAG}_bench_$1_$2_acquisition.err || exit 5
 done
 # two ranks on this one GPU over gloo: exercises the sharded bench path (the numbers mean nothing)

@@ -24,7 +24,8 @@ rows = [("default", "c4_500x300k banded (the `bench.py` default)"),
         ("venice1800_banded_rows", "venice1800 banded, rows of A materialised (`SFM_BA_STATE=0`)"), ("venice1800_uniform", "venice1800 uniform (dense S, 12 600 unknowns)")]
 for w in ("c4_500x300k", "venice1800"):
     for v, what in (("loop", "one lap closing a loop"), ("closures", "two laps over the same places")):
-        rows.append((f"{w}_{v}", f"{w} {what}, cameras in the folded order"))
+        rows.append((f"{w}_{v}", f"{w} {what}, split: near points fused, far points camera-pair, solve in the folded order"))
+        rows.append((f"{w}_{v}_folded", f"{w} {what}, all cameras in the folded order (`SFM_BA_SPLIT=0`)"))
         rows.append((f"{w}_{v}_acquisition", f"{w} {what}, cameras in acquisition order (`SFM_BA_REORDER=0`)"))
 out = [f"# profiles — round {tag[1:]} evidence (MI355X, one GPU)", "",
        "Produced by `bash scripts/gpu_evidence.sh <tag>` on the GPU box; this file is generated from the files next to it",

@@ -113,6 +113,8 @@ class SplitProblem:
         cols = (7 * bk[:, None, None] + a[None, None, :])
         flat = (rows * n7 + cols).reshape(-1)
         self.far_blocks = int(bj.size)
+        # blocks of S only the far points fill (near points never couple cameras a window apart)
+        self.n_blocks = int(near.plan.n_blocks + np.count_nonzero(bj - bk >= MAX_WINDOW))
         self.far_entries = torch.from_numpy(flat).to(d)
         self.order_dev = torch.from_numpy(order.astype(np.int32)).to(d)
         self.pos_dev = torch.from_numpy(pos.astype(np.int64)).to(d)
