@@ -164,6 +164,10 @@ class SplitProblem:
         near.ssq.add_(far.ssq)
         _lib.check(lib.sfm_ba_cost_finish(p(near.ssq), self.m, p(near.cost_buf), _stream()))
 
+    def set_state(self, C=None, P=None):
+        """Override the derived camera centre / projection (shared by both problems)."""
+        self.near.set_state(C=C, P=P)
+
     def cost(self) -> float:
         self.cost_async()
         return float(self.cost_buf.item())

@@ -105,7 +105,11 @@ def test_drop_in_entry_with_reorder():
     from sfm_amd import synthetic
     from sfm_amd.frame import Frame, Map
 
+    from sfm_amd.split import SplitProblem
+
     p = synthetic.make_problem(40, 2500, 5, visibility="loop", seed=12)
+    # the entry takes the split for this problem
+    assert SplitProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true).far.n > 0
     frames_a, map_a = synthetic.to_frames_and_map(p, Frame, Map, extra_keypoints=3)
     frames_b, map_b = copy.deepcopy(frames_a), copy.deepcopy(map_a)
     ca = ba.optimize_using_BA(frames_a, map_a, verbose=False, max_iter=3, threshold=0.0)
