@@ -10,8 +10,9 @@ pytestmark = pytest.mark.gpu
 # (cameras, points, views, visibility) -> path of the solve on the folded system:
 # 7m = 2100, band ~90: superblocks of 128; 7m = 1400, band <= 64: 64-blocks; 7m = 280: general path
 # (whole lower triangle renumbered); two laps, 7m = 3500, band ~240: superblocks of 256
+# and the benchmark's size (500 cameras x 300 000 points x 1.95 M observations, one lap)
 CASES = [(300, 30000, (6, 7), "loop"), (200, 20000, (3, 4), "loop"), (40, 3000, 5, "loop"),
-         (500, 40000, (6, 7), "closures")]
+         (500, 40000, (6, 7), "closures"), (500, 300000, (6, 7), "loop")]
 
 
 @pytest.mark.parametrize("m,n,k,vis", CASES)
