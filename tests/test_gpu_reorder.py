@@ -120,3 +120,35 @@ def test_drop_in_entry_with_reorder():
         assert np.max(np.abs(fa.P - fb.P)) < 1e-8 * np.max(np.abs(fa.P))
     assert np.array_equal(frames_b[0].R, p.R[0])
     assert np.max(np.abs(map_a.X - map_b.X)) < 1e-8 * np.max(np.abs(map_a.X))
+
+
+@pytest.mark.parametrize("m,n,k,block", [(300, 30000, (6, 7), 128), (500, 40000, (12, 14), 256)])
+def test_superblock_solve_accuracy_on_a_real_system(m, n, k, block):
+    """The reduction on superblocks on an assembled, ill-conditioned S (not a diagonally dominant
+    random matrix): at least as close to an extended-precision solution as numpy's LU, within 5x."""
+    import sfm_amd  # noqa: F401
+    from sfm_amd import _lib, synthetic
+    from sfm_amd.device import DeviceProblem
+
+    p = synthetic.make_problem(m, n, k, visibility="loop", seed=31)
+    prob = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true, reorder=True)
+    n7 = prob.n7
+    assert int(_lib.load().sfm_ba_reduced_solve_block(n7, prob.half_bandwidth)) == block
+    prob.camera_prepare()
+    prob.jacobian()
+    prob.assemble(0.5)
+    S = prob.S[:n7].cpu().numpy().copy()
+    e = prob.S[n7].cpu().numpy().copy()
+    S = np.tril(S) + np.tril(S, -1).T
+    prob.solve()
+    prob.check_flags()
+    x_dev = prob.delta_a.cpu().numpy().reshape(-1)
+    x_lu = np.linalg.solve(S, e)
+    Sl, el, x = S.astype(np.longdouble), e.astype(np.longdouble), x_lu.astype(np.longdouble)
+    for _ in range(6):
+        x = x + np.linalg.solve(S, (el - Sl @ x).astype(np.float64)).astype(np.longdouble)
+    x = x.astype(np.float64)
+    err_dev = np.linalg.norm(x_dev - x) / np.linalg.norm(x)
+    err_lu = np.linalg.norm(x_lu - x) / np.linalg.norm(x)
+    print(f"7m = {n7}, half bandwidth {prob.half_bandwidth}: device {err_dev:.2e}, numpy LU {err_lu:.2e}")
+    assert err_dev <= max(5.0 * err_lu, 1e-10)
