@@ -287,7 +287,8 @@ int32_t sfm_ba_reduced_solve_block(int32_t n7, int32_t half_bandwidth);
 /* The system of src/sparse_ba.py:274-276 with its cameras renumbered, for a caller that assembles in
  * the frames' order and solves in an order with a narrower band: row / column 7 p + a of d_S_out is
  * row / column 7 d_cam_order[p] + a of d_S (both [(n7+1) x n7], right-hand side in row n7; d_cam_order
- * [n7 / 7] = the camera at position p).  Only the lower triangle of d_S is read; of d_S_out the
+ * [n7 / 7] = the camera at position p: a permutation of 0 .. n7/7 - 1, which the call cannot check -
+ * an index outside that range is an out-of-bounds read on the device).  Only the lower triangle of d_S is read; of d_S_out the
  * lower-triangle entries within half_bandwidth of the diagonal and row n7 are written (pass n7 to
  * get the whole lower triangle; for a band path pass 2 * sfm_ba_reduced_solve_block(...) - 1, what
  * that path reads).  The solution of the renumbered system is delta_a in the new order:

@@ -32,17 +32,24 @@ def half_bandwidth(cam_pos, cam_idx, pt_idx, n_points: int) -> int:
     return int(7 * np.max(hi[seen] - lo[seen]) + 6)
 
 
-def breadth_first_positions(cam_idx, pt_idx, n_cams: int, n_points: int):
-    """(position of every camera, camera at every position) for the breadth-first order of the
-    co-visibility graph from camera 0; cameras that no chain of shared points links to camera 0
-    follow, component by component."""
+def covisibility_graph(cam_idx, pt_idx, n_cams: int, n_points: int):
+    """Sparse (n_cams, n_cams) matrix with a non-zero (j, k) where cameras j and k share a point
+    (the block pattern of S, diagonal included)."""
     from scipy.sparse import csr_matrix
-    from scipy.sparse.csgraph import breadth_first_order
 
     cam = np.asarray(cam_idx, dtype=np.int64)
     pt = np.asarray(pt_idx, dtype=np.int64)
     V = csr_matrix((np.ones(cam.shape[0], dtype=np.float32), (pt, cam)), shape=(n_points, n_cams))
-    G = (V.T @ V).tocsr()
+    return (V.T @ V).tocsr()
+
+
+def breadth_first_positions(cam_idx, pt_idx, n_cams: int, n_points: int, graph=None):
+    """(position of every camera, camera at every position) for the breadth-first order of the
+    co-visibility graph from camera 0; cameras that no chain of shared points links to camera 0
+    follow, component by component."""
+    from scipy.sparse.csgraph import breadth_first_order
+
+    G = covisibility_graph(cam_idx, pt_idx, n_cams, n_points) if graph is None else graph
     seen = np.zeros(n_cams, dtype=bool)
     parts = []
     for root in range(n_cams):
@@ -67,23 +74,20 @@ def reorder_observations(cam_pos, cam_idx, pt_idx, x_true):
             np.asarray(x_true)[order], order)
 
 
-def spectral_positions(cam_idx, pt_idx, n_cams: int, n_points: int):
+def spectral_positions(cam_idx, pt_idx, n_cams: int, n_points: int, graph=None):
     """(position of every camera, camera at every position) by the second eigenvector of the
     Laplacian of the co-visibility graph (unit weights): along a sequence that folds back on
     itself the eigenvector varies with the place, not with the time of acquisition, so sorting
     by it interleaves the passes through the same place.  None when the graph is not connected,
     when it is so dense that no order gives a band (more than 128 neighbours per camera on
     average), or when the eigen-solver does not converge."""
-    from scipy.sparse import csr_matrix, diags
+    from scipy.sparse import diags
     from scipy.sparse.csgraph import connected_components
     from scipy.sparse.linalg import eigsh
 
     if n_cams < 3:
         return None
-    cam = np.asarray(cam_idx, dtype=np.int64)
-    pt = np.asarray(pt_idx, dtype=np.int64)
-    V = csr_matrix((np.ones(cam.shape[0], dtype=np.float32), (pt, cam)), shape=(n_points, n_cams))
-    G = (V.T @ V).tocsr()
+    G = (covisibility_graph(cam_idx, pt_idx, n_cams, n_points) if graph is None else graph).copy()
     G.data[:] = 1.0
     G.setdiag(0.0)
     G.eliminate_zeros()
@@ -113,8 +117,9 @@ def narrowest_order(cam_idx, pt_idx, n_cams: int, n_points: int, natural_half_ba
     if hb is None:
         hb = half_bandwidth(np.arange(n_cams), cam_idx, pt_idx, n_points)
     best = (int(hb), None, None)
-    for cand in (breadth_first_positions(cam_idx, pt_idx, n_cams, n_points),
-                 spectral_positions(cam_idx, pt_idx, n_cams, n_points)):
+    G = covisibility_graph(cam_idx, pt_idx, n_cams, n_points)
+    for cand in (breadth_first_positions(cam_idx, pt_idx, n_cams, n_points, G),
+                 spectral_positions(cam_idx, pt_idx, n_cams, n_points, G)):
         if cand is None:
             continue
         h = half_bandwidth(cand[0], cam_idx, pt_idx, n_points)

@@ -132,6 +132,8 @@ class SplitProblem:
     def iterate_async(self, mu=None):
         near, far, lib, p = self.near, self.far, self.lib, _lib.ptr
         mu = self.MU if mu is None else mu
+        if not mu > 0:
+            raise ValueError("the split flow needs damping (mu > 0), as the fused assembly does")
         n7 = self.n7
         if not near._blk_fresh:
             near.camera_prepare()
