@@ -273,8 +273,8 @@ int sfm_ba_solve_reduced(double* d_S, int32_t n7, double* d_delta_a, void* d_cho
 /* The same solve (src/sparse_ba.py:274-276) for a caller that knows S[r][c] = 0 wherever
  * |r - c| > half_bandwidth (sfm_ba_plan_half_bandwidth).  With half_bandwidth <= 64 the factorisation
  * is a chain of 64 x 64 blocks that one workgroup walks in a single launch, substitutions included,
- * and d_S is only read; with 64 < half_bandwidth <= 256 and enough unknowns (7m above ~900 for a
- * band up to 128, above ~3100 up to 256) the same reduction runs on superblocks of 128 or 256
+ * and d_S is only read; with 64 < half_bandwidth <= 256 and enough unknowns (7m above 384 for a
+ * band up to 128, above 1280 up to 256) the same reduction runs on superblocks of 128 or 256
  * unknowns, d_S again only read; anything else takes the general path of sfm_ba_solve_reduced
  * (d_S destroyed).  The band paths read whole blocks - entries up to twice the block edge
  * (sfm_ba_reduced_solve_block) below the diagonal, which must hold their zeros - and nothing beyond. */

@@ -65,21 +65,26 @@ def test_banded_paths_match_numpy(n, hb):
 
 
 # bands wider than one 64-block: cyclic reduction on superblocks of 2 or 4 tiles (128, 256 unknowns)
-# with 9, 9 (partial last one), 33 and 14, 13 superblocks; (600, 100), (1300, 200) and (2500, 300) have
-# too few superblocks or too wide a band for it and go through the general path
-WIDE_CASES = [(1100, 128), (1030, 70), (4200, 65), (3400, 130), (3300, 200), (600, 100), (1300, 200), (2500, 300)]
+# with 9, 9 (partial last one), 33, 5 and 14, 13, 6 superblocks; (2500, 300) has too wide a band and
+# (900, 200) too few superblocks for it: general path
+WIDE_CASES = [(1100, 128, 128), (1030, 70, 128), (4200, 65, 128), (600, 100, 128), (3400, 130, 256), (3300, 200, 256),
+              (1300, 200, 256), (2500, 300, 0), (900, 200, 0)]
 
 
-@pytest.mark.parametrize("n,hb", WIDE_CASES)
-def test_wide_band_reduction_matches_numpy(n, hb):
+@pytest.mark.parametrize("n,hb,expected_block", WIDE_CASES)
+def test_wide_band_reduction_matches_numpy(n, hb, expected_block):
     S, e = _system(n, hb, seed=n)
     x_ref = np.linalg.solve(S, e)
     x, info, S_after = _solve(S, e, hb, banded_entry=True)
     assert info == 0
     assert np.linalg.norm(x - x_ref) <= 1e-12 * np.linalg.norm(x_ref)
     # the reduction only reads the matrix; the general path factors it in place
-    on_superblocks = (hb <= 128 and -(-n // 128) >= 8) or (128 < hb <= 256 and -(-n // 256) >= 13)
-    assert np.array_equal(S_after, S) == on_superblocks
+    import sfm_amd  # noqa: F401
+    from sfm_amd import _lib
+
+    block = int(_lib.load().sfm_ba_reduced_solve_block(n, hb))
+    assert block == expected_block
+    assert np.array_equal(S_after, S) == (block != 0)
 
 
 def test_wide_band_takes_general_path():

@@ -108,4 +108,6 @@ def test_permute_system_by_hand():
     assert lib.sfm_ba_reduced_solve_block(3500, 90) == 128
     assert lib.sfm_ba_reduced_solve_block(3500, 200) == 256
     assert lib.sfm_ba_reduced_solve_block(3500, 300) == 0
-    assert lib.sfm_ba_reduced_solve_block(700, 90) == 0
+    assert lib.sfm_ba_reduced_solve_block(700, 90) == 128
+    assert lib.sfm_ba_reduced_solve_block(350, 90) == 0
+    assert lib.sfm_ba_reduced_solve_block(1200, 200) == 0
