@@ -286,15 +286,23 @@ def stage_times(prob, steps, warmup, world, barrier):
     return dt, _lib.profile_read(), final_cost
 
 
+STATE_KERNELS = ("k_fused_state", "k_back_substitute_state")
+
+
 def stage_groups(prof, steps, N, n, m, s_blocks, pmc):
-    """Per-stage record: time, the bytes the loop must move (headline GB/s) and the same with B priced
-    as a materialised array, counter traffic where a PMC pass of these kernels is on file."""
+    """Per-stage record: time, what bounds the stage, the stage's algorithmic bytes (and the same with B
+    priced as a materialised array), counter traffic where a PMC pass of these kernels is on file.
+    A stage whose kernel reads rows of A from memory is HBM-bound and `GBps` = algorithmic bytes / time
+    is its achieved bandwidth.  A stage whose kernel forms the rows itself (k_fused_state,
+    k_back_substitute_state) moves a fraction of those bytes and is bound by the fp64 pipe: for it the
+    same quotient is reported as `priced_GBps` - the rate at which the stage's algorithmic bytes are
+    retired, which may exceed the HBM peak and is not a bandwidth - and `traffic_GBps` is what it moves."""
     alg, alg_b = algorithmic_bytes(N, n, m, s_blocks), algorithmic_bytes(N, n, m, s_blocks, with_B=True)
     stages = dict(GROUPS)
     if "k_fused_state" in prof:
-        # the rows of A are formed inside the assembly kernel: one stage does the work of two, and is
-        # priced with the bytes of both (what the two stages would have to move between them).  A split
-        # problem also runs the Jacobian and camera-pair kernels, over its few far points: same stage.
+        # the rows of A are formed inside the assembly kernel: one stage does the work of two and is
+        # priced with the bytes of both (what the two stages would have to move between them).  The far
+        # points of the plan go through the Jacobian and camera-pair kernels: same stage.
         stages = {"jacobian+assembly": list(GROUPS["jacobian"]) + list(GROUPS["assembly"]),
                   "back_substitution": GROUPS["back_substitution"]}
         for d in (alg, alg_b):
@@ -306,13 +314,65 @@ def stage_groups(prof, steps, N, n, m, s_blocks, pmc):
         traffic = None
         if present and all(nm in pmc for nm in present):
             traffic = sum(pmc[nm]["bytes"] * prof[nm][1] / steps for nm in present)
-        groups[g] = {"ms": ms, "kernels": present, "bytes": alg[g],
-                     "GBps": alg[g] / (ms * 1e-3) / 1e9 if ms > 0 else None,
-                     "bytes_with_B": alg_b[g],
-                     "GBps_with_B": alg_b[g] / (ms * 1e-3) / 1e9 if ms > 0 else None,
-                     "traffic": traffic,
-                     "traffic_GBps": traffic / (ms * 1e-3) / 1e9 if traffic and ms > 0 else None}
+        forms_rows = any(nm in STATE_KERNELS for nm in present)
+        rate = alg[g] / (ms * 1e-3) / 1e9 if ms > 0 else None
+        rate_b = alg_b[g] / (ms * 1e-3) / 1e9 if ms > 0 else None
+        rec = {"ms": ms, "kernels": present, "bound": "fp64" if forms_rows else "hbm",
+               "algorithmic_bytes": alg[g], "algorithmic_bytes_with_B": alg_b[g]}
+        if forms_rows:
+            rec.update({"priced_GBps": rate, "priced_GBps_with_B": rate_b})
+        else:
+            rec.update({"GBps": rate, "GBps_with_B": rate_b})
+        rec.update({"traffic": traffic,
+                    "traffic_GBps": traffic / (ms * 1e-3) / 1e9 if traffic and ms > 0 else None})
+        groups[g] = rec
     return groups
+
+
+def roofline_record(prof, groups, plan):
+    """The `roofline` object of the line: the stage that takes the longest, against the ceiling that
+    bounds its slowest kernel."""
+    dominant = max(groups, key=lambda g: groups[g]["ms"])
+    gr = groups[dominant]
+    slowest = max(gr["kernels"], key=lambda nm: prof[nm][0])
+    name = (f"{dominant} stage ({'+'.join(gr['kernels'])}; slowest kernel {slowest}, "
+            f"{prof[slowest][0] / prof[slowest][1] * 1e3:.1f} us per launch)")
+    if gr["bound"] == "hbm":
+        return {
+            "bound": "hbm", "kernel": name, "achieved": gr["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gr["GBps"] / HBM_PEAK_GBS, "traffic": gr["traffic"],
+            "achieved_with_B": gr["GBps_with_B"], "frac_with_B": gr["GBps_with_B"] / HBM_PEAK_GBS, "groups": groups,
+            "note": "achieved = algorithmic bytes of the stage / HIP-event time of its kernels: 136 / 152 / 120 bytes per "
+                    "observation for Jacobian / assembly / back-substitution (B = -dF/dC is part of the rows of A and "
+                    "never written); *_with_B adds B as a materialised array (184 / 200 / 168)",
+        }
+    # the fused kernel forms the rows of A itself: what it moves is a fraction of the stage's algorithmic
+    # bytes and what bounds it is the fp64 pipe of the SIMDs, which the matrix and the vector instructions share
+    kn = "k_fused_state"
+    slots = plan.fused_slots
+    tiles = 2 if slots <= 4 else (3 if slots <= 7 else 4)
+    mfma_flops = plan.n_steps * (tiles * (tiles + 1) // 2) * 6 * 2048.0
+    t = prof[kn][0] / prof[kn][1] * 1e-3
+    tf = mfma_flops / t / 1e12
+    return {
+        "bound": "mfma", "kernel": name, "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": tf / FP64_PEAK_TFLOPS, "traffic": gr["traffic"],
+        "traffic_GBps": gr["traffic_GBps"],
+        "traffic_frac_of_hbm_peak": gr["traffic_GBps"] / HBM_PEAK_GBS if gr["traffic_GBps"] else None,
+        "matrix_flops": mfma_flops,
+        "achieved_algorithmic": gr["priced_GBps"], "achieved_algorithmic_unit": "GB/s",
+        "frac_algorithmic": gr["priced_GBps"] / HBM_PEAK_GBS,
+        "achieved_algorithmic_with_B": gr["priced_GBps_with_B"],
+        "frac_algorithmic_with_B": gr["priced_GBps_with_B"] / HBM_PEAK_GBS,
+        "groups": groups,
+        "note": "the dominant kernel forms the rows of A in registers and is bound by the fp64 pipe, not by HBM: achieved = "
+                "v_mfma_f64_16x16x4 flops it executes per launch (lower-triangle tiles x 6 per step of 8 points) / its "
+                "HIP-event time, against the dense fp64 peak; the same pipe also executes the kernel's vector fp64 "
+                "arithmetic, about as many cycles again.  traffic = HBM bytes per iteration of the stage from the "
+                "committed PMC passes (null: no pass for this workload).  achieved_algorithmic prices the bytes the two "
+                "stages it replaces would have to move (136 + 152 bytes per observation, 184 + 200 with B) over the "
+                "stage's time: the rate at which that work is retired, not bytes moved",
+    }
 
 
 def solve_record(prof, steps, n7, hb):
@@ -349,13 +409,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None,
                     help="default: c4_500x300k (weak scaling), venice1800 (strong scaling)")
-    ap.add_argument("--visibility", default="banded", choices=["banded", "uniform", "closures", "loop"])
+    ap.add_argument("--visibility", default="banded", choices=["banded", "uniform", "closures", "loop", "tracks"])
+    ap.add_argument("--shuffle-ids", action="store_true",
+                    help="relabel the point ids at random (the plan sorts the points itself)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's point count per GPU; strong: one problem sharded over the GPUs")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-uniform-record", action="store_true",
-                    help="skip the short extra runs of the same workload with uniform visibility and as a closed loop")
+    ap.add_argument("--no-uniform-record", "--no-extra-records", dest="no_uniform_record", action="store_true",
+                    help="skip the short extra runs (other visibility patterns of the same size, the 1 M-point workload)")
     ap.add_argument("--triangulate", type=int, default=0, metavar="N",
                     help="benchmark the two-view triangulation kernel on N correspondences instead")
     ap.add_argument("--pnp", type=int, default=0, metavar="N",
@@ -398,10 +460,9 @@ def main():
         return
 
     import sfm_amd  # noqa: F401
-    from sfm_amd import _lib, synthetic
+    from sfm_amd import _lib, ordering, synthetic
     from sfm_amd.device import DeviceProblem
-    from sfm_amd.split import SplitProblem
-    from sfm_amd.dist import local_problem, packed_system_elements
+    from sfm_amd.dist import local_problem, packed_system_elements, shard_bounds
 
     if os.environ.get("SFM_BA_BENCH_WATCHDOG"):
         # a rank that is still running after this many seconds prints where every thread stands and exits
@@ -425,43 +486,81 @@ def main():
         else:
             dist.init_process_group(backend)
         group = dist.group.WORLD
-
-    m, n_workload, k = synthetic.WORKLOADS[args.workload]
-    n_total = n_workload * world if args.scaling == "weak" else n_workload
-    full = synthetic.make_workload(args.workload, visibility=args.visibility, seed=args.seed, points=n_total)
-    N_total = full.n_obs
-    if world > 1:
-        prob_h, _ = local_problem(full, rank, world)
-    else:
-        prob_h = full
-    del full
-    revisits = world == 1 and args.visibility in ("loop", "closures") and os.environ.get("SFM_BA_REORDER", "1") != "0"
-    prob = None
-    if revisits and os.environ.get("SFM_BA_SPLIT", "1") != "0":
-        # sequences that revisit places: near points through the fused assembly, far points through the
-        # camera-pair kernels, band solve in the folded camera order
-        try:
-            prob = SplitProblem(prob_h.K, prob_h.R, prob_h.T, prob_h.X, prob_h.cam_idx, prob_h.pt_idx, prob_h.x_true,
-                                n_cams=m, plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"))
-        except ValueError:
-            prob = None
-    if prob is None:
-        # (for revisits with the split refused or switched off: all cameras in the folded order,
-        # camera-pair assembly)
-        prob = DeviceProblem(prob_h.K, prob_h.R, prob_h.T, prob_h.X, prob_h.cam_idx, prob_h.pt_idx, prob_h.x_true,
-                             n_cams=m, group=group, check=(world == 1),
-                             plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"),
-                             steps=bool(int(os.environ.get("SFM_BA_STEPS", "0"))), reorder=revisits)
-    is_split = isinstance(prob, SplitProblem)
-    fused_plan = prob.near.plan if is_split else prob.plan  # the plan whose runs the fused kernels walk
-    n_blocks = prob.n_blocks if is_split else prob.plan.n_blocks
-    N_loc, n_loc = prob.N, prob.n
+    plan_where = os.environ.get("SFM_BA_PLAN_WHERE", "device")
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def describe(prob):
+        pl = prob.plan
+        if not (pl.fused and prob.from_state):
+            return "fused point-major on materialised rows of A" if pl.fused else "camera-pair"
+        txt = f"fused point-major, rows of A formed in the kernel ({pl.n_near} near points in {pl.n_keys} windows of " \
+              f"{pl.fused_slots} cameras"
+        if pl.n_far:
+            txt += f"; {pl.n_far} far points with {pl.n_far_obs} observations through the camera-pair kernels"
+        return txt + ")"
+
+    def order_text(prob):
+        if prob.cam_order is None:
+            return "acquisition order"
+        nat = prob.natural_half_bandwidth
+        return (f"folded (half bandwidth {nat if nat is not None else '?'} in acquisition order, {prob.half_bandwidth} "
+                f"folded; on the device)")
+
+    def sub_record(workload, visibility, steps, shuffle_ids=False, reorder=False, n_points=None):
+        """A short run of another workload / visibility on this GPU: stage times, solve, what bounds what."""
+        mm = synthetic.WORKLOADS[workload][0]
+        q = synthetic.make_workload(workload, visibility=visibility, seed=args.seed, points=n_points, shuffle_ids=shuffle_ids)
+        pr = DeviceProblem(q.K, q.R, q.T, q.X, q.cam_idx, q.pt_idx, q.x_true, n_cams=mm, check=True, plan_where=plan_where,
+                           reorder=reorder)
+        sdt, sprof, cost = stage_times(pr, steps, 2, 1, barrier)
+        pr.check_flags()
+        nb = 2 * pr.plan.n_blocks - mm
+        groups = stage_groups(sprof, steps, pr.N, pr.n, mm, nb, measured_traffic(workload, visibility))
+        rec = {
+            "workload": f"{workload}: {mm} cameras x {q.n} points x {q.n_obs} observations, {visibility} visibility"
+                        + (", point ids relabelled at random" if shuffle_ids else ""),
+            "steps": steps, "ms_per_step": sdt / steps * 1e3, "value": q.n_obs * steps / sdt, "unit": "obs/s",
+            "nonzero_S_blocks": nb, "camera_order": order_text(pr), "assembly": describe(pr), "final_cost": cost,
+            "roofline": roofline_record(sprof, groups, pr.plan),
+            "solve": solve_record(sprof, steps, 7 * mm, pr.half_bandwidth),
+        }
+        del pr, q
+        torch.cuda.empty_cache()
+        return rec
+
+    m, n_workload, k = synthetic.WORKLOADS[args.workload]
+    n_total = n_workload * world if args.scaling == "weak" else n_workload
+    full = synthetic.make_workload(args.workload, visibility=args.visibility, seed=args.seed, points=n_total,
+                                   shuffle_ids=args.shuffle_ids)
+    N_total = full.n_obs
+    revisits = args.visibility in ("loop", "closures") and os.environ.get("SFM_BA_REORDER", "1") != "0"
+    cam_order = None
+    imbalance = None
+    if world > 1:
+        if revisits:
+            # every rank computes the same camera order from the unsharded lists (deterministic), so that
+            # the shards agree on the band they exchange
+            hb_nat = ordering.half_bandwidth(np.arange(m), full.cam_idx, full.pt_idx, full.n)
+            hb_new, pos, order = ordering.narrowest_order(full.cam_idx, full.pt_idx, m, full.n, hb_nat)
+            if pos is not None and 2 * hb_new <= hb_nat:
+                cam_order = order
+        prob_h, _ = local_problem(full, rank, world)
+        bounds = shard_bounds(full.pt_idx, full.n, world)
+        per_rank = np.diff(np.searchsorted(np.sort(full.pt_idx), bounds))
+        imbalance = float(per_rank.max() / per_rank.mean())
+    else:
+        prob_h = full
+    del full
+    prob = DeviceProblem(prob_h.K, prob_h.R, prob_h.T, prob_h.X, prob_h.cam_idx, prob_h.pt_idx, prob_h.x_true,
+                         n_cams=m, group=group, check=(world == 1), plan_where=plan_where,
+                         reorder=revisits and world == 1, cam_order=cam_order)
+    n_blocks = prob.plan.n_blocks
+    N_loc, n_loc = prob.N, prob.n
 
     # timed region: K iterations after W warm-up iterations
     dt, prof, final_cost = stage_times(prob, args.steps, args.warmup, world, barrier)
@@ -488,50 +587,26 @@ def main():
     for name, v in _lib.profile_read().items():
         prof.setdefault(name, v)
 
+    allreduce_ms = None
+    if world > 1:
+        # the exchange alone: K all-reduces of the buffer an iteration exchanges, outside the timed region
+        buf = prob.compact if prob.band_sharded else prob.tri
+        if buf is not None:
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                prob._all_reduce(buf)
+            barrier()
+            allreduce_ms = (time.perf_counter() - t2) / args.steps * 1e3
+
     if rank == 0:
         per_kernel = {name: {"ms_avg": ms / cnt, "launches_per_step": cnt / args.steps} for name, (ms, cnt) in prof.items()}
         s_blocks = 2 * n_blocks - m  # plan counts pairs j <= k
-        pmc = measured_traffic(args.workload, args.visibility) if world == 1 else {}
+        pmc = measured_traffic(args.workload, args.visibility) if world == 1 and not args.shuffle_ids else {}
         groups = stage_groups(prof, args.steps, N_loc, n_loc, m, s_blocks, pmc)
-        # the dominant HBM-bound stage; its algorithmic bytes are defined per stage, so a stage that
-        # takes several kernels is priced as one unit (the slowest kernel inside it is named)
-        dominant = max(groups, key=lambda g: groups[g]["ms"])
-        slowest = max(groups[dominant]["kernels"], key=lambda nm: prof[nm][0])
-        roofline = {
-            "bound": "hbm",
-            "kernel": f"{dominant} stage ({'+'.join(groups[dominant]['kernels'])}; slowest kernel {slowest}, "
-                      f"{prof[slowest][0] / prof[slowest][1] * 1e3:.1f} us per launch)",
-            "achieved": groups[dominant]["GBps"],
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": groups[dominant]["GBps"] / HBM_PEAK_GBS,
-            "traffic": groups[dominant]["traffic"],
-            "achieved_with_B": groups[dominant]["GBps_with_B"],
-            "frac_with_B": groups[dominant]["GBps_with_B"] / HBM_PEAK_GBS,
-            "groups": groups,
-            "note": "achieved / frac and every group's GBps price the algorithmic bytes of the stages: 136 / 152 / 120 "
-                    "bytes per observation for Jacobian / assembly / back-substitution (B = -dF/dC is part of the rows "
-                    "of A and never written); the *_with_B fields add B as a materialised array (184 / 200 / 168), the "
-                    "form in which the reference hands the blocks between its stages.  Where one kernel forms the rows "
-                    "of A and assembles from them (jacobian+assembly) it is priced with the bytes of both stages; its "
-                    "real traffic (the traffic field) is far smaller, because A never goes to memory, and what "
-                    "bounds it is the fp64 pipe, not HBM",
-        }
-        if fused_plan.fused and ("k_fused_state" in prof or "k_fused_runs" in prof):
-            # the fused kernel is bound by the fp64 pipe (matrix and vector instructions share it), not by
-            # HBM: matrix-instruction flops it executes per launch, exactly, against the fp64 peak
-            kn = "k_fused_state" if "k_fused_state" in prof else "k_fused_runs"
-            slots = fused_plan.fused_slots
-            tiles = 2 if slots <= 4 else (3 if slots <= 7 else 4)
-            mfma_flops = fused_plan.n_steps * (tiles * (tiles + 1) // 2) * 6 * 2048.0
-            t = prof[kn][0] / prof[kn][1] * 1e-3
-            roofline["fp64_pipe"] = {
-                "kernel": kn, "matrix_flops": mfma_flops, "achieved": mfma_flops / t / 1e12, "peak": FP64_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": mfma_flops / t / 1e12 / FP64_PEAK_TFLOPS,
-                "note": "v_mfma_f64_16x16x4 flops only (tiles x 6 per step of 8 points); the same pipe also executes "
-                        "the kernel's vector fp64 arithmetic, about as many cycles again",
-            }
+        roofline = roofline_record(prof, groups, prob.plan)
         n7 = 7 * m
+        solve = solve_record(prof, args.steps, n7, prob.half_bandwidth)
         out = {
             "metric": "BA Gauss-Newton observations/sec (synthetic %d cams x %d pts)" % (m, n_total),
             "value": N_total * args.steps / dt,
@@ -549,76 +624,43 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: {m} cameras x {n_total} points x {N_total} observations, "
-                            f"{args.visibility} visibility, seed {args.seed}, "
+                            f"{args.visibility} visibility" + (", point ids relabelled at random" if args.shuffle_ids else "")
+                            + f", seed {args.seed}, "
                             + (f"{n_workload} points per GPU" if args.scaling == "weak"
                                else f"one problem sharded by point id over {world} GPU(s)"),
                 "cameras": m, "points": n_total, "observations": N_total, "visibility": args.visibility,
                 "nonzero_S_blocks": s_blocks,
-                "camera_order": ("acquisition order" if prob.cam_order is None else
-                                 f"folded (half bandwidth {prob.natural_half_bandwidth} in acquisition order, "
-                                 f"{prob.half_bandwidth} folded"
-                                 + ("; only the solve sees the folded order)" if is_split else "; on the device)")),
-                "assembly": (f"split: fused point-major with the rows of A formed in the kernel for {prob.near.n} near "
-                             f"points, camera-pair for {prob.far.n} far points" if is_split
-                             else "fused point-major, rows of A formed in the kernel" if prob.from_state and prob.plan.fused
-                             else "fused point-major" if prob.plan.fused else "camera-pair"),
+                "camera_order": order_text(prob),
+                "assembly": describe(prob),
                 "parallelism": "1 gpu" if world == 1 else f"point-id sharding x{world}, all-reduce of "
                                f"{packed_system_elements(m, prob.half_bandwidth) * 8 / 1e6:.1f} MB per iteration",
             },
             "final_cost": final_cost,
             "roofline": roofline,
-            "solve": solve_record(prof, args.steps, n7, prob.half_bandwidth),
+            "solve": solve,
             "kernels": per_kernel,
         }
-        if world == 1 and args.visibility == "banded" and not args.no_uniform_record:
-            # the same workload with every point seen by cameras drawn uniformly: dense S, camera-pair assembly
+        if world > 1:
+            out["multi_gpu"] = {
+                "allreduce_ms": allreduce_ms, "allreduce_MB": packed_system_elements(m, prob.half_bandwidth) * 8 / 1e6,
+                "solve_ms": solve["ms"], "observations_per_rank_max_over_mean": imbalance,
+                "note": "allreduce_ms: the exchange buffer of one iteration all-reduced alone, outside the timed region; "
+                        "solve_ms: the replicated reduced solve (rank 0).  Both are the parts of an iteration that do not "
+                        "shrink with the number of GPUs",
+            }
+        if world == 1 and args.visibility == "banded" and not args.shuffle_ids and not args.no_uniform_record:
+            # short runs of the same size with other visibility patterns, and of the 1 M-point workload
             del prob
             torch.cuda.empty_cache()
-            u = synthetic.make_workload(args.workload, visibility="uniform", seed=args.seed, points=n_total)
-            up = DeviceProblem(u.K, u.R, u.T, u.X, u.cam_idx, u.pt_idx, u.x_true, n_cams=m, check=True,
-                               plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"))
             usteps = max(2, min(args.steps, 5))
-            udt, uprof, _ = stage_times(up, usteps, 2, 1, barrier)
-            up.check_flags()
-            ub = 2 * up.plan.n_blocks - m
-            out["uniform_visibility"] = {
-                "workload": f"{args.workload}: {m} cameras x {u.n} points x {u.n_obs} observations, uniform visibility",
-                "steps": usteps, "ms_per_step": udt / usteps * 1e3, "value": u.n_obs * usteps / udt, "unit": "obs/s",
-                "nonzero_S_blocks": ub,
-                "groups": stage_groups(uprof, usteps, up.N, up.n, m, ub, measured_traffic(args.workload, "uniform")),
-                "solve": solve_record(uprof, usteps, n7, up.half_bandwidth),
-            }
-            del up, u
-            torch.cuda.empty_cache()
-            # and as one lap that ends where it started (a closed loop): cameras kept in the folded order,
-            # camera-pair assembly, band solve
+            out["shuffled_ids"] = sub_record(args.workload, "banded", usteps, shuffle_ids=True, n_points=n_total)
+            out["tracks_visibility"] = sub_record(args.workload, "tracks", usteps, n_points=n_total)
+            out["uniform_visibility"] = sub_record(args.workload, "uniform", usteps, n_points=n_total)
             if m >= 4 * (k if isinstance(k, int) else k[1]):
-                lp = synthetic.make_workload(args.workload, visibility="loop", seed=args.seed, points=n_total)
-                try:
-                    lprob = SplitProblem(lp.K, lp.R, lp.T, lp.X, lp.cam_idx, lp.pt_idx, lp.x_true, n_cams=m,
-                                         plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"))
-                except ValueError:
-                    lprob = DeviceProblem(lp.K, lp.R, lp.T, lp.X, lp.cam_idx, lp.pt_idx, lp.x_true, n_cams=m, check=True,
-                                          plan_where=os.environ.get("SFM_BA_PLAN_WHERE", "device"), reorder=True)
-                ldt, lprof, _ = stage_times(lprob, usteps, 2, 1, barrier)
-                lprob.check_flags()
-                lsplit = isinstance(lprob, SplitProblem)
-                lb = 2 * (lprob.n_blocks if lsplit else lprob.plan.n_blocks) - m
-                out["loop_visibility"] = {
-                    "workload": f"{args.workload}: {m} cameras x {lp.n} points x {lp.n_obs} observations, "
-                                "one lap closing a loop",
-                    "camera_order": ("acquisition order" if lprob.cam_order is None else
-                                     f"folded (half bandwidth {lprob.natural_half_bandwidth} in acquisition order, "
-                                     f"{lprob.half_bandwidth} folded)"),
-                    "assembly": (f"split: fused point-major for {lprob.near.n} near points, camera-pair for "
-                                 f"{lprob.far.n} far points, system renumbered for the solve" if lsplit
-                                 else "camera-pair, cameras kept in the folded order"),
-                    "steps": usteps, "ms_per_step": ldt / usteps * 1e3, "value": lp.n_obs * usteps / ldt, "unit": "obs/s",
-                    "nonzero_S_blocks": lb,
-                    "groups": stage_groups(lprof, usteps, lprob.N, lprob.n, m, lb, {}),
-                    "solve": solve_record(lprof, usteps, n7, lprob.half_bandwidth),
-                }
-                del lprob, lp
+                # one lap that ends where it started (a closed loop): cameras kept in the folded order
+                out["loop_visibility"] = sub_record(args.workload, "loop", usteps, reorder=True, n_points=n_total)
+            if args.workload != "venice1800":
+                out["venice1800_banded"] = sub_record("venice1800", "banded", usteps)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.visibility, args.seed)
         print(json.dumps(out))

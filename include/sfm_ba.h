@@ -86,10 +86,13 @@ void sfm_ba_plan_destroy(sfm_ba_plan* plan);
  * 2 slot_cam, 3 tp_ptr, 4 pair_entry, 5 grp_pt, 6 cam_obs (empty when the caller order is
  * camera-sorted), 7-9 per-camera items (camera, begin, end), 10 cam_item_ptr, 11-12 block cameras
  * (j, k), 13 pair entries (two uint32 each), 14-17 pair items (block, begin, end, partial), 18-20
- * split blocks (block, first partial, partials), 21-29 runs of the fused assembly (first point of
- * each run, base camera, observation per (point, window slot), runs grouped by window: row pointer
- * and run ids, first run of every range of points that one wave walks, first point and run of every
- * step of 8 points, first step of every range; all empty when the plan has no runs).  *bytes receives the array's size; h_dst may be
+ * split blocks (block, first partial, partials); the fused assembly (all empty when the plan has no
+ * runs): 21 first position of each run, 22 window of each run, 23 observation per (position, window
+ * slot), 24 cameras of each window, 25 first run of each window, 26 first run of every range of positions
+ * one wave walks, 27 point id at each position, 28 cameras of each run (for the kernels' loads), 29-30
+ * per block the (window, slot, slot) entries the finishing kernel adds, 31-32 per block the far plan's
+ * partial results, 33 far point ids, 34-37 per far observation: observation, camera, far point number,
+ * point id.  *bytes receives the array's size; h_dst may be
  * null to query it, otherwise `capacity` must be at least that size. */
 int sfm_ba_plan_read(const sfm_ba_plan* plan, int field, void* h_dst, int64_t capacity, int64_t* bytes);
 /* sizes: what[0]=n_cams, [1]=n_pts, [2]=n_obs, [3]=number of camera-pair blocks (j<=k) with a shared
@@ -101,19 +104,28 @@ int sfm_ba_plan_sizes(const sfm_ba_plan* plan, int64_t what[8]);
  * point).  `Indices.shared_point_indices` (src/sparse_ba.py:107-128) is where the reference finds
  * the same empty blocks, one pair at a time.  A sharded run takes the maximum over its ranks. */
 int32_t sfm_ba_plan_half_bandwidth(const sfm_ba_plan* plan);
-/* Runs of the fused assembly.  When every point's cameras lie within 8 consecutive camera ids (what
- * an incremental reconstruction produces: `Map.update_map`, src/map.py:17-37, appends points as
- * frames are registered) the plan also groups consecutive points into runs that share a window of
- * 6 or 8 cameras, and sfm_ba_schur_assemble - called without d_B, weights, d_U, d_eps_a and
- * d_cam_red, with mu > 0 - then forms V^-1, eps_b, S and e in a single pass over d_A.
- *   info[0] = 1 when that path will be taken, [1] = cameras per window (0: pattern not eligible),
- *   [2] = first-cameras that share a window, [3] = largest run length in points, [4] = runs,
+/* The fused assembly and its near / far split of the points.  A point seen by at most 4..8 cameras
+ * (the width is chosen per plan from the observations' histogram) is "near": the plan sorts the near
+ * points by the window of cameras they are seen from - consecutive cameras where the point's cameras
+ * span no more than the width (what an incremental reconstruction produces: `Map.update_map`,
+ * src/map.py:17-37, appends points as frames are registered; any order of the point ids), otherwise the
+ * point's own camera set - and cuts that order into runs of one window each; sfm_ba_schur_assemble_state
+ * (and sfm_ba_schur_assemble called without d_B, weights, d_U, d_eps_a and d_cam_red, with mu > 0) then
+ * forms V^-1, eps_b and the near points' share of S and e in a single pass.  Points with more cameras,
+ * and points whose window would hold fewer than 4 points, are "far": they form a plan of their own
+ * (sfm_ba_plan_far, NULL when there is none) that goes through the camera-pair kernels, and the
+ * finishing kernel adds both shares into S.  The reference's `Indices` / calc_S
+ * (src/sparse_ba.py:58-97, 237-258) take any index order and any camera set; so does this.
+ *   info[0] = 1 when that path will be taken, [1] = cameras per window (0: no fused path),
+ *   [2] = near points, [3] = largest run length in points, [4] = runs,
  *   [5] = windows, [6] = steps (groups of up to 8 consecutive points of one run), [7] = ranges of
- *   points (one wave each).  sfm_ba_plan_set_fused(plan, 0) turns the path off for this plan (tests compare
- *   the two paths); both give the same S and e to rounding.  No counterpart in the reference, whose
- *   calc_S (src/sparse_ba.py:237-258) walks camera pairs. */
+ *   positions (one wave each).  sfm_ba_plan_set_fused(plan, 0) turns the path off for this plan (tests
+ *   compare the two paths); both give the same S and e to rounding. */
 int sfm_ba_plan_fused_info(const sfm_ba_plan* plan, int32_t info[8]);
 int sfm_ba_plan_set_fused(sfm_ba_plan* plan, int enable);
+/* the plan over the far points' observations (owned by `plan`; NULL: every point is near, or the plan
+ * has no fused path).  Its points are the far points renumbered 0 .. in ascending id. */
+const sfm_ba_plan* sfm_ba_plan_far(const sfm_ba_plan* plan);
 /* bytes of the scratch workspace the assemble / back-substitution entry points need */
 int64_t sfm_ba_plan_workspace_bytes(const sfm_ba_plan* plan);
 
@@ -181,7 +193,7 @@ int sfm_ba_schur_assemble(const sfm_ba_plan* plan, const double* d_A, const doub
                           void* d_workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Jacobian blocks and Schur assembly in one pass, for plans with runs (sfm_ba_plan_state_path
+ * Jacobian blocks and Schur assembly in one pass, for plans with a fused path (sfm_ba_plan_state_path
  * returns 1): the rows of A and the residuals - compute_A_B and the projection of get_indices
  * (src/bundle_adjustment.py:22-67, src/jacobian.py:21-220, src/utils.py:8-11) - are formed inside
  * the assembly kernel from the prepared camera records (sfm_ba_camera_prepare), the projection
@@ -197,33 +209,12 @@ int sfm_ba_schur_assemble_state(const sfm_ba_plan* plan, const double* d_cam_blk
                                 double* d_V_inv, double* d_eps_b, void* d_workspace, void* stream);
 /* calc_delta_b (src/sparse_ba.py:279-290) the same way: the rows of A are formed again from the camera
  * records and d_X (the state the system was assembled at: call it before the cameras are updated).
+ * d_workspace: the workspace the preceding sfm_ba_schur_assemble_state call on this state used (it
+ * holds the rows of the far points' observations, which are not formed a second time).
  * update_points != 0: d_X += x_step * delta_b afterwards (src/bundle_adjustment.py:100), point by point. */
 int sfm_ba_back_substitute_state(const sfm_ba_plan* plan, const double* d_cam_blk, const double* d_V_inv,
                                  const double* d_eps_b, const double* d_delta_a, double* d_delta_b, double* d_X,
-                                 int update_points, double x_step, void* stream);
-
-/* ------------------------------------------------------------------------------------------
- * The same three stages on "step blocks", for plans with runs (sfm_ba_plan_fused_info): the layout
- * the loop uses when nobody needs A in the reference's [N,2,7] form.  A step is up to 8 consecutive
- * points of one run; its block holds, for every (point, camera slot of the run's window), the row
- * of A and the residual x_true - x_pred as 8 pieces of 16 bytes (zeros where the point has no
- * observation by that camera), piece-major, so that a wave reads or writes a block as 8 contiguous
- * KiB.  d_steps: sfm_ba_plan_steps_elements(plan) doubles (8 KiB per step).
- *   sfm_ba_jacobian_steps        : compute_A_B + the projection of get_indices
- *                                  (src/bundle_adjustment.py:22-67, src/jacobian.py:21-220) into d_steps
- *   sfm_ba_schur_assemble_steps  : calc_V_inv ... calc_e (src/sparse_ba.py:147-271) from d_steps; mu > 0;
- *                                  d_S (lower triangle), d_e, d_V_inv, d_eps_b as sfm_ba_schur_assemble
- *                                  writes them without by-products
- *   sfm_ba_back_substitute_steps : calc_delta_b (src/sparse_ba.py:279-290) and the point update
- * ---------------------------------------------------------------------------------------- */
-int64_t sfm_ba_plan_steps_elements(const sfm_ba_plan* plan);
-int sfm_ba_jacobian_steps(const sfm_ba_plan* plan, const double* d_cam_blk, const double* d_P, const double* d_X,
-                          const double* d_x_true, double* d_steps, void* stream);
-int sfm_ba_schur_assemble_steps(const sfm_ba_plan* plan, const double* d_steps, double mu, double mu_u, double* d_S,
-                                double* d_e, double* d_V_inv, double* d_eps_b, void* d_workspace, void* stream);
-int sfm_ba_back_substitute_steps(const sfm_ba_plan* plan, const double* d_steps, const double* d_V_inv,
-                                 const double* d_eps_b, const double* d_delta_a, double* d_delta_b, double* d_X_update,
-                                 double x_step, void* stream);
+                                 int update_points, double x_step, void* d_workspace, void* stream);
 
 /* W [N,7,3] and Y [N,7,3] as the reference materialises them (calc_W, calc_Y,
  * src/sparse_ba.py:215-234).  Not needed by the solve; provided for callers that inspect them. */

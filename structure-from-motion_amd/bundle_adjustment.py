@@ -43,19 +43,10 @@ def _flatten(frames):
 def _problem_from(frames, map_, check=True, reorder=False):
     K, R, T, C, P = _pack_frames(frames)
     vi, pi, x_t = _flatten(frames)
-    prob = None
-    if reorder:
-        # sequences that revisit places: near / far points split when that applies, else all cameras
-        # in the order that narrows the band
-        from .split import SplitProblem
-
-        try:
-            prob = SplitProblem(K, R, T, np.asarray(map_.X)[:, :3], vi, pi, x_t, n_cams=len(frames), check=check)
-        except ValueError:
-            prob = None
-    if prob is None:
-        prob = DeviceProblem(K, R, T, np.asarray(map_.X)[:, :3], vi, pi, x_t, n_cams=len(frames), check=check,
-                             reorder=reorder)
+    # (reorder: sequences that revisit places are kept on the device in the camera order that narrows
+    # the band of the reduced system)
+    prob = DeviceProblem(K, R, T, np.asarray(map_.X)[:, :3], vi, pi, x_t, n_cams=len(frames), check=check,
+                         reorder=reorder)
     prob.set_state(C=C, P=P)
     return prob, vi, pi, x_t
 
@@ -89,8 +80,7 @@ def optimize_using_BA(frames, map_, verbose=True, max_iter=50, threshold=100.0, 
     the first and ``map_.X[:, :3]`` in place.  Returns the per-iteration costs (the
     reference returns None and prints them).  ``reorder`` (not in the reference): for sequences
     that revisit places, solve with the cameras in the order that narrows the band of the reduced
-    system (``sfm_amd.ordering``; ``sfm_amd.split`` when only a few points span distant cameras);
-    results are the same to rounding and come back per frame."""
+    system (``sfm_amd.ordering``); results are the same to rounding and come back per frame."""
     prob, vi, pi, _ = _problem_from(frames, map_, check=True, reorder=reorder)
     # check_args of the step (src/sparse_ba.py:39-46)
     if not can_run_ba(prob.m, prob.n, prob.N, 7, 3):

@@ -47,16 +47,6 @@ int sfm_ba_schur_assemble(const sfm_ba_plan* plan, const double* d_A, const doub
                          d_eps_b, d_cam_red, d_workspace, static_cast<hipStream_t>(stream));
 }
 
-int64_t sfm_ba_plan_steps_elements(const sfm_ba_plan* plan) {
-  return plan && plan->n_runs > 0 ? (int64_t)plan->n_steps * 1024 : 0;
-}
-
-int sfm_ba_jacobian_steps(const sfm_ba_plan* plan, const double* d_cam_blk, const double* d_P, const double* d_X,
-                          const double* d_x_true, double* d_steps, void* stream) {
-  if (!plan || !d_cam_blk || !d_P || !d_X || !d_x_true || !d_steps || plan->n_runs <= 0) return SFM_BA_EINVAL;
-  return launch_jacobian_steps(plan, d_cam_blk, d_P, d_X, d_x_true, d_steps, static_cast<hipStream_t>(stream));
-}
-
 int sfm_ba_plan_state_path(const sfm_ba_plan* plan) { return plan && fz_state_applies(plan) ? 1 : 0; }
 
 int sfm_ba_schur_assemble_state(const sfm_ba_plan* plan, const double* d_cam_blk, const double* d_P, const double* d_X,
@@ -70,27 +60,12 @@ int sfm_ba_schur_assemble_state(const sfm_ba_plan* plan, const double* d_cam_blk
 
 int sfm_ba_back_substitute_state(const sfm_ba_plan* plan, const double* d_cam_blk, const double* d_V_inv,
                                  const double* d_eps_b, const double* d_delta_a, double* d_delta_b, double* d_X,
-                                 int update_points, double x_step, void* stream) {
-  if (!plan || !d_cam_blk || !d_V_inv || !d_eps_b || !d_delta_a || !d_delta_b || !d_X) return SFM_BA_EINVAL;
+                                 int update_points, double x_step, void* d_workspace, void* stream) {
+  if (!plan || !d_cam_blk || !d_V_inv || !d_eps_b || !d_delta_a || !d_delta_b || !d_X || !d_workspace)
+    return SFM_BA_EINVAL;
   if (!fz_state_applies(plan)) return SFM_BA_EINVAL;
   return launch_back_substitute_state(plan, d_cam_blk, d_V_inv, d_eps_b, d_delta_a, d_delta_b, d_X, update_points,
-                                      x_step, static_cast<hipStream_t>(stream));
-}
-
-int sfm_ba_schur_assemble_steps(const sfm_ba_plan* plan, const double* d_steps, double mu, double mu_u, double* d_S,
-                                double* d_e, double* d_V_inv, double* d_eps_b, void* d_workspace, void* stream) {
-  if (!plan || !d_steps || !d_V_inv || !d_eps_b || !d_workspace || plan->n_runs <= 0) return SFM_BA_EINVAL;
-  if (!(mu > 0.0) || !(mu_u >= 0.0)) return SFM_BA_EINVAL;
-  return launch_assemble_fused(plan, nullptr, nullptr, nullptr, d_steps, mu, mu_u, d_S, d_e, d_V_inv, d_eps_b,
-                               d_workspace, static_cast<hipStream_t>(stream));
-}
-
-int sfm_ba_back_substitute_steps(const sfm_ba_plan* plan, const double* d_steps, const double* d_V_inv,
-                                 const double* d_eps_b, const double* d_delta_a, double* d_delta_b, double* d_X_update,
-                                 double x_step, void* stream) {
-  if (!plan || !d_steps || !d_V_inv || !d_eps_b || !d_delta_a || !d_delta_b || plan->n_runs <= 0) return SFM_BA_EINVAL;
-  return launch_back_substitute_steps(plan, d_steps, d_V_inv, d_eps_b, d_delta_a, d_delta_b, d_X_update, x_step,
-                                      static_cast<hipStream_t>(stream));
+                                      x_step, d_workspace, static_cast<hipStream_t>(stream));
 }
 
 int sfm_ba_calc_W_Y(const sfm_ba_plan* plan, const double* d_A, const double* d_B, const double* d_weights,

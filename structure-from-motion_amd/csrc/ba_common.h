@@ -16,33 +16,91 @@ constexpr int kPairChunk = 512;   // (obs, obs) entries per camera-pair work ite
 constexpr int kPairPad = 64;
 constexpr int kPairPartStride = 56;  // doubles per partial result of a split block: 7x7 block + e_j        // valid records / T rows kept behind the last entry
 
-// One (observation, observation) pair of a camera-pair block, as byte offsets (the kernel that walks
-// these adds a piece offset and issues the fetch; N * 112 < 2^32 is checked when the plan is built)
-// Fused point-major assembly ("runs"): a run is a range of consecutive points whose cameras all lie in
-// one window of `slots` consecutive camera ids starting at the run's base camera; lane (point, slot)
-// of a wave then owns one observation or none, 8 points per step.
+// Fused point-major assembly.  The plan sorts the points it can handle this way ("near" points) by the
+// window of cameras they are seen from and walks them by position in that order:
+//   window  a list of up to `slots` (4..8) cameras.  A point whose cameras span at most `slots`
+//           consecutive ids uses a window of consecutive cameras (base = first camera rounded down to a
+//           multiple of slots - span + 1, so that points with nearby first cameras share it); a point
+//           with at most `slots` cameras that lie further apart uses its own camera set as the window
+//   run     consecutive positions of one window, cut at multiples of pmax; lane (point, slot) of a
+//           wave then owns one observation or none, 8 points per step
+// Points with more cameras than a window holds, and points whose window would hold fewer than
+// kFzMinWindowPoints points, are "far": they go through the camera-pair kernels of a second plan over
+// their observations, and the finishing kernel adds both kinds into S.
 constexpr int kFzLanesPerPoint = 8;  // lanes (= slot positions of the table) per point
 constexpr int kFzMaxPmax = 1024;     // longest range of points one wave walks (and with it: runs per range)
 constexpr int kFzMaxRunsPerRange = 256;  // what the kernel that forms A itself keeps of a range's run boundaries
+constexpr int kFzMinWindowPoints = 4;    // a window with fewer points is not worth a partial result of its own
 constexpr int kFzSlotSums = 35;      // per-camera-slot sums behind a partial's tiles: 28 (upper triangle of
                                      // sum A^T A) + 7 (sum A^T g); 7 more per extra row
-struct FzShape {
-  int slots;  // camera slots of a window: 4 .. 8
-  int group;  // consecutive first-cameras that share a window: slots - span + 1
-  int pmax;   // a run is cut wherever the point id is a multiple of this
-};
-// Shape of the runs for n points whose cameras span at most span_max consecutive ids; false when the
-// fused path does not apply (a point without observations, or a span beyond 8 cameras).
-inline bool fz_shape(int32_t n, int32_t span_max, bool empty_point, FzShape* o) {
-  if (empty_point || span_max < 1 || span_max > 8) return false;
-  o->slots = span_max < 4 ? 4 : span_max;
-  o->group = o->slots - span_max + 1;
-  int pm = ((n + 2047) / 2048 + 7) & ~7;
-  o->pmax = pm < 32 ? 32 : (pm > kFzMaxPmax ? kFzMaxPmax : pm);
+// Cameras per window for a plan, from two histograms over the points with at most 8 cameras: obs_by_k[v]
+// / obs_by_span[v] = observations of the points with v cameras / with a camera span of v (spans
+// beyond 8: not counted).  The smallest width that keeps 98 % of what a width of 8 would keep; measured
+// on the span when at least half of those observations belong to points that fit a window of
+// consecutive cameras, otherwise on the camera count.  0: no point qualifies.
+inline int fz_choose_slots(const int64_t obs_by_k[9], const int64_t obs_by_span[9]) {
+  int64_t tot_k = 0, tot_s = 0;
+  for (int v = 1; v <= 8; ++v) {
+    tot_k += obs_by_k[v];
+    tot_s += obs_by_span[v];
+  }
+  if (tot_k == 0) return 0;
+  const int64_t* h = 2 * tot_s >= tot_k ? obs_by_span : obs_by_k;
+  const int64_t tot = 2 * tot_s >= tot_k ? tot_s : tot_k;
+  int64_t acc = 0;
+  for (int v = 1; v <= 8; ++v) {
+    acc += h[v];
+    if (v >= 4 && 50 * acc >= 49 * tot) return v;
+  }
+  return 8;
+}
+// a run is cut wherever the position is a multiple of this: one wave per range of pmax near points
+inline int fz_pmax_for(int32_t n_near) {
+  const int pm = ((n_near + 2047) / 2048 + 7) & ~7;
+  return pm < 32 ? 32 : (pm > kFzMaxPmax ? kFzMaxPmax : pm);
+}
+// the fused path is taken when the runs hold a step's worth of points on average (a run costs a partial
+// result of its own, about what two steps cost) and the near points are a fair share of all points
+inline bool fz_worthwhile(int32_t n, int32_t n_near, int32_t n_runs) {
+  return n_near > 0 && (int64_t)n_runs * 8 <= (int64_t)n_near + 1536 && (int64_t)n_near * 8 >= (int64_t)n;
+}
+// sort key of a near candidate: windows of consecutive cameras first, by base camera, then the
+// camera-set windows by a hash of the set (equal sets get equal keys; different sets with equal
+// hashes only cost run length, the windows are told apart by comparing the cameras)
+__host__ __device__ inline uint32_t fz_hash_cams(const int32_t* cams, int k) {
+  uint32_t h = 2166136261u;
+  for (int i = 0; i < k; ++i) {
+    h ^= (uint32_t)cams[i] + 0x9e3779b9u + (h << 6) + (h >> 2);
+    h *= 16777619u;
+  }
+  return h;
+}
+// Window of a point with cameras cams[0..k) (ascending) in a plan with `slots` cameras per window and
+// m cameras: fills desc[0..8) (-1: no camera at that slot) and the sort key; false when the point does
+// not fit a window (k = 0 or k > slots).
+__host__ __device__ inline bool fz_point_window(const int32_t* cams, int k, int slots, int m, int32_t desc[8],
+                                                uint64_t* key) {
+  if (k < 1 || k > slots) return false;
+  const int span = cams[k - 1] - cams[0] + 1;
+  if (span <= slots) {
+    const int g = slots - span + 1;
+    int base = cams[0] / g * g;
+    const int last = m - slots > 0 ? m - slots : 0;  // windows do not reach past the last camera
+    if (base > last) base = last;
+    for (int s = 0; s < 8; ++s) desc[s] = (s < slots && base + s < m) ? base + s : -1;
+    *key = (uint64_t)(uint32_t)base;
+  } else {
+    for (int s = 0; s < 8; ++s) desc[s] = s < k ? cams[s] : -1;
+    *key = (uint64_t(1) << 32) | fz_hash_cams(cams, k);
+  }
   return true;
 }
-// runs must be long enough for their fixed cost (one partial result each) to be small
-inline bool fz_worthwhile(int32_t n, int32_t n_runs) { return (int64_t)n_runs * 24 <= (int64_t)n + 1536; }
+// slot of camera c in the window desc (the camera is there)
+__host__ __device__ inline int fz_slot_of(const int32_t desc[8], int32_t c) {
+  for (int s = 0; s < 8; ++s)
+    if (desc[s] == c) return s;
+  return -1;
+}
 // the 7 * slots rows of a window: 16 per row tile of the matrix cores, the rest ("extra rows") summed by the lanes
 __host__ __device__ inline int fz_row_tiles(int slots) { return slots <= 4 ? 2 : (slots <= 7 ? 3 : 4); }
 __host__ __device__ inline int fz_extra_rows(int slots) { return slots == 7 ? 1 : 0; }
@@ -56,6 +114,8 @@ __host__ __device__ inline int64_t fz_part_stride(int slots) {
   return fz_part_stride_c(fz_row_tiles(slots), fz_extra_rows(slots));
 }
 
+// One (observation, observation) pair of a camera-pair block, as byte offsets (the kernel that walks
+// these adds a piece offset and issues the fetch; N * 112 < 2^32 is checked when the plan is built)
 struct PairEntry {
   uint32_t row_a;  // 112 * observation (caller order) of the block's row camera j: its row of A
   uint32_t row_b;  // off the diagonal (j < k): 112 * observation of camera k, same point.  On the
@@ -103,23 +163,42 @@ struct sfm_ba_plan {
   int32_t* d_mb_blk = nullptr;
   int32_t* d_mb_part = nullptr;   // first partial
   int32_t* d_mb_cnt = nullptr;    // number of partials
-  // fused point-major assembly (fz_slots = 0: the visibility pattern does not allow it)
-  int32_t fz_slots = 0, fz_group = 0, fz_pmax = 0, fz_enabled = 1;
+  // fused point-major assembly over the near points (fz_slots = 0: the plan has none)
+  int32_t fz_slots = 0, fz_pmax = 0, fz_enabled = 1;
+  int32_t n_near = 0;             // near points = positions of the tables below
   int32_t n_runs = 0, n_keys = 0, n_ranges = 0, n_steps = 0;
-  int32_t fz_max_range_runs = 0;  // most runs inside one range of fz_pmax points
-  int32_t* d_run_pt0 = nullptr;   // [n_runs+1] first point of each run
-  int32_t* d_run_base = nullptr;  // [n_runs] first camera of the run's window
-  int32_t* d_rng_run = nullptr;   // [n_ranges+1] first run of every range of fz_pmax points (one wave per range)
-  // steps: up to 8 consecutive points of one run; the steps of a run, of a range and of the plan are consecutive
-  int32_t* d_step_pt0 = nullptr;  // [n_steps] first point of the step
-  int32_t* d_step_run = nullptr;  // [n_steps + 1] its run (entry n_steps: n_runs)
-  int32_t* d_rng_step = nullptr;  // [n_ranges+1] first step of every range
-  int32_t* d_slot_obs = nullptr;  // [n][8] observation (caller order) of point i at camera base + slot, or -1
-  int32_t* d_key_ptr = nullptr;   // [n_keys+1] runs grouped by window (key = base / group), ascending run id
-  int32_t* d_key_run = nullptr;   // [n_runs]
+  int32_t fz_max_range_runs = 0;  // most runs inside one range of fz_pmax positions
+  int32_t* d_fz_pt = nullptr;     // [n_near] point id at every position
+  int32_t* d_slot_obs = nullptr;  // [n_near][8] observation (caller order) of the point at that position by the
+                                  // camera at that slot of its window, or -1
+  int32_t* d_run_pt0 = nullptr;   // [n_runs+1] first position of each run
+  int32_t* d_run_key = nullptr;   // [n_runs] window of the run
+  int32_t* d_run_cam = nullptr;   // [n_runs][8] cameras of the run's window, for the kernels' loads: a slot
+                                  // without a camera repeats the window's first camera
+  int32_t* d_rng_run = nullptr;   // [n_ranges+1] first run of every range of fz_pmax positions (one wave per range)
+  int32_t* d_key_cam = nullptr;   // [n_keys][8] camera at every slot of the window, -1: none
+  int32_t* d_key_run = nullptr;   // [n_keys+1] first run of every window (the runs of a window are consecutive)
+  // per camera-pair block (the plan's blocks, j <= k): where the finishing kernel finds its sums
+  int32_t* d_fb_ptr = nullptr;    // [n_blocks+1] entries of the block in d_fb_ent
+  int32_t* d_fb_ent = nullptr;    // [n_fb] window << 6 | slot of camera j << 3 | slot of camera k
+  int32_t* d_fb_far_part = nullptr;  // [n_blocks] first partial result of the block in the far plan's workspace
+  int32_t* d_fb_far_cnt = nullptr;   // [n_blocks] number of those partials (0: the far points do not touch the block)
+  int32_t n_fb = 0;
+  // far points: a plan of their own over their observations, points renumbered 0 .. n_far - 1 in
+  // ascending id, observations in the caller's relative order
+  sfm_ba_plan* far = nullptr;
+  int32_t n_far = 0;
+  int64_t n_far_obs = 0;
+  int32_t* d_far_pt = nullptr;    // [n_far] point id of far point q
+  int32_t* d_far_obs = nullptr;   // [n_far_obs] observation (caller order) of far observation i
+  int32_t* d_far_cam = nullptr;   // [n_far_obs] its camera
+  int32_t* d_far_lpt = nullptr;   // [n_far_obs] its far point number
+  int32_t* d_far_gpt = nullptr;   // [n_far_obs] its point id (= d_far_pt[d_far_lpt[i]])
+  int32_t force_parts = 0;        // this plan is the far plan of another: every block writes partial results
   int64_t device_bytes = 0;
   // workspace section offsets (bytes)
-  int64_t ws_g = 0, ws_T = 0, ws_campart = 0, ws_spart = 0, ws_fpart = 0, ws_fkey = 0, ws_fzero = 0, ws_total = 0;
+  int64_t ws_g = 0, ws_T = 0, ws_campart = 0, ws_spart = 0, ws_fpart = 0, ws_fkey = 0, ws_fzero = 0, ws_far_A = 0,
+          ws_far_xt = 0, ws_far_xp = 0, ws_far = 0, ws_total = 0;
 };
 
 namespace sfmba {
@@ -168,14 +247,14 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
                     double* U, double* eps_a, double* Vinv, double* eps_b, double* cam_red,
                     void* ws, hipStream_t st);
 // the fused path of launch_assemble (plan with runs, no weights, no by-products, B taken from A)
-// (steps: the step blocks of launch_jacobian_steps, or null to gather the operands from A, xt, xp)
-int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* xt, const double* xp,
-                          const double* steps, double mu, double mu_u, double* S, double* e, double* Vinv,
-                          double* eps_b, void* ws, hipStream_t st);
-int launch_jacobian_steps(const sfm_ba_plan* p, const double* blk, const double* P, const double* X, const double* xt,
-                          double* steps, hipStream_t st);
-int launch_back_substitute_steps(const sfm_ba_plan* p, const double* steps, const double* Vinv, const double* eps_b,
-                                 const double* da, double* db, double* Xupd, double x_step, hipStream_t st);
+int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* xt, const double* xp, double mu,
+                          double mu_u, double* S, double* e, double* Vinv, double* eps_b, void* ws, hipStream_t st);
+// the camera-pair path of a far plan (see sfm_ba_plan::far): partial results only, points renumbered by pt_map
+int launch_assemble_parts(const sfm_ba_plan* p, const int32_t* pt_map, const double* A, const double* xt,
+                          const double* xp, double mu, double* Vinv, double* eps_b, void* ws, hipStream_t st);
+int launch_back_substitute_mapped(const sfm_ba_plan* p, const int32_t* pt_map, const double* A, const double* Vinv,
+                                  const double* eps_b, const double* da, double* db, double* Xupd, double x_step,
+                                  hipStream_t st);
 int launch_calc_W_Y(const sfm_ba_plan* p, const double* A, const double* B, const double* w,
                     const double* Vinv, const int32_t* pt, double* W, double* Y, hipStream_t st);
 int launch_add_diagonal(double* S, int n7, double mu, hipStream_t st);
@@ -184,7 +263,8 @@ int launch_assemble_state(const sfm_ba_plan* p, const double* blk, const double*
                           double mu, double mu_u, double* S, double* e, double* Vinv, double* eps_b, void* ws,
                           hipStream_t st);
 int launch_back_substitute_state(const sfm_ba_plan* p, const double* blk, const double* Vinv, const double* eps_b,
-                                 const double* da, double* db, double* X, int update, double x_step, hipStream_t st);
+                                 const double* da, double* db, double* X, int update, double x_step, void* ws,
+                                 hipStream_t st);
 int launch_status(const double* cost, const int32_t* info, const int32_t* fa, const int32_t* fb, int m, double* out,
                   hipStream_t st);
 int launch_lower_pack(const double* S, int n7, double* tri, hipStream_t st);

@@ -1,8 +1,8 @@
 // Fused point-major Schur assembly for gfx950 (MI355X): calc_V_inv, calc_W, calc_Y, calc_S, calc_U,
 // calc_epsilon_*, calc_e of the reference (src/sparse_ba.py:147-271) in one pass over A.
 //
-// Applies when the plan found "runs": ranges of consecutive points whose cameras all lie in a window
-// of 6 or 8 consecutive camera ids (the visibility an incremental reconstruction produces).  Then
+// Applies to the plan's "near" points: the plan keeps them sorted by the window of (up to 8) cameras
+// they are seen from and cuts that order into runs of one window each (ba_common.h).  Then
 //   S_window -= sum_i Y_i W_i^T,   Y_i = W_i V_i^-1,   W_i = [A_ij^T B_ij]_j  (7 rows per camera j)
 // is a dense contraction over the points of the run: with V_i^-1 = G_i^T G_i and Z_i = W_i G_i^T it
 // is the symmetric rank-3 update sum_i Z_i Z_i^T, and a wave accumulates it with v_mfma_f64_16x16x4
@@ -12,7 +12,7 @@
 // window is as small as the visibility allows (no tile of padding) and the per-point arithmetic
 // avoids divisions.
 //
-// One wave per range of pmax points (a range holds whole runs), no barriers; the operand fetches
+// One wave per range of pmax positions (a range holds whole runs), no barriers; the operand fetches
 // run two steps ahead and do not stop at the end of a run.  Lane (p, s) of a step owns the observation of point p (8 points per
 // step) by the camera at slot s of the window (or none: it then contributes zeros):
 //   1. the row of A, x_true and x_pred come straight into registers (loads for the next step are
@@ -111,19 +111,16 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 // rows for W = 5 on two row tiles cost 42 registers more than a third row of tiles and spilled).
 //   W = 4: T 2, E 0 (28 rows)   W = 5: T 3, E 0 (35)   W = 6: T 3, E 0 (42)   W = 7: T 3, E 1 (49)
 //   W = 8: T 4, E 0 (56)
-// BLOCKED: the operands come from the step blocks k_jacobian_steps wrote (block k = step k of the
-// plan: 8 pieces of 1 KiB, piece q holding 16 bytes per lane: the row of A in pieces 0..6, the
-// residual x_true - x_pred in piece 7), every load a whole contiguous KiB; otherwise they are
-// gathered row by row from A, x_true and x_pred in the caller's order through the slot table.
+// The operands are gathered row by row from A, x_true and x_pred in the caller's order through the
+// slot table; V^-1 and eps_b go to the point's id (fz_pt: point id at every position).
 // what lanes of k_fused_runs without an observation read as their operands: zeros, never written
 __device__ __align__(256) const double g_fz_zero_row[32] = {0.0};
 
-template <int W, int T, int E, int WPS, bool BLOCKED>  // WPS: waves per SIMD the register allocation leaves room for
+template <int W, int T, int E, int WPS>  // WPS: waves per SIMD the register allocation leaves room for
 __global__ __launch_bounds__(64, WPS) void k_fused_runs(
     const int32_t* __restrict__ rng_run, const int32_t* __restrict__ run_pt0,
-    const int32_t* __restrict__ slot_obs, const double* __restrict__ A,
-    const double* __restrict__ xt, const double* __restrict__ xp, const int32_t* __restrict__ rng_step,
-    const double2* __restrict__ Ab, double mu, double* __restrict__ Vinv,
+    const int32_t* __restrict__ slot_obs, const int32_t* __restrict__ fz_pt, const double* __restrict__ A,
+    const double* __restrict__ xt, const double* __restrict__ xp, double mu, double* __restrict__ Vinv,
     double* __restrict__ eps_b, double* __restrict__ part, int pmax,
     int n_pts) {
   static_assert(16 * T + E >= 7 * W && 16 * T <= 7 * W + 15, "tiles and extra rows must cover the window");
@@ -134,7 +131,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
   constexpr int64_t STRIDE = fz_part_stride_c(T, E);
   __shared__ __attribute__((aligned(16))) double Zp[24 * KS];  // [K column = 3 point + q][8 slot + r]
   __shared__ int bnd[kFzMaxPmax + 1];  // first point of every run of this wave's range, and the range's end
-#define FZ_RESIDUAL_IN_ROWS BLOCKED
+#define FZ_RESIDUAL_IN_ROWS false
   const int lane = threadIdx.x;
   const double* zero_row = g_fz_zero_row;
   const int p = lane >> 3, s = lane & 7;
@@ -165,11 +162,6 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
   // address keeps the loads unconditional, so that they land in the registers of av[] themselves)
 #define FZ_FETCH_ROWS(pos)                                                    \
   do {                                                                        \
-    if (BLOCKED) {                                                            \
-      const double2* bp_ = Ab + (int64_t)kfetch * 512 + lane;                 \
-      _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) av[q_] = bp_[64 * q_]; \
-      break;                                                                  \
-    }                                                                         \
     const bool has_ = (pos) >= 0;                                             \
     const double* ap_ = has_ ? A + 14 * (int64_t)(pos) : zero_row;            \
     const double* tp_ = has_ ? xt + 2 * (int64_t)(pos) : zero_row;            \
@@ -189,9 +181,11 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
   } while (0)
 #define FZ_LIM(r) __builtin_amdgcn_readfirstlane(bnd[(r) + 1])
   // the first step's table entries do not need the boundaries: they are on their way meanwhile
+  // point id of the lane's point in the step that starts at position `first`
+#define FZ_FETCH_PID(first) fz_pt[(unsigned)(((first) + p) < n_pts ? (first) + p : n_pts - 1)]
   const int pt_first = f0 + p < n_pts ? f0 + p : n_pts - 1;
-  const int pos_raw = BLOCKED ? 0 : slot_obs[(unsigned)(kFzLanesPerPoint * pt_first + s)];
-  int kfetch = BLOCKED ? rng_step[blockIdx.x] : 0;  // step whose block the next fetch reads
+  const int pos_raw = slot_obs[(unsigned)(kFzLanesPerPoint * pt_first + s)];
+  int pid = fz_pt[(unsigned)pt_first];
   for (int i = lane; i <= nr; i += 64) bnd[i] = run_pt0[run0 + i];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -205,10 +199,11 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
   FZ_FETCH_ROWS(pos);
   int f1 = f0, r1 = r0;
   FZ_ADVANCE(f1, r1);
-  int pos_next = !BLOCKED && r1 < nr ? FZ_FETCH_POS(f1, FZ_LIM(r1)) : -1;
+  int pos_next = r1 < nr ? FZ_FETCH_POS(f1, FZ_LIM(r1)) : -1;
+  int pid_next = r1 < nr ? FZ_FETCH_PID(f1) : 0;
   int f2 = f1, r2 = r1;
   if (r2 < nr) FZ_ADVANCE(f2, r2);
-  int pos_next2 = !BLOCKED && r2 < nr ? FZ_FETCH_POS(f2, FZ_LIM(r2)) : -1;
+  int pos_next2 = r2 < nr ? FZ_FETCH_POS(f2, FZ_LIM(r2)) : -1;
 
   d4_t acc[NT];
 #pragma unroll
@@ -250,12 +245,13 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     pos = pos_next;
-    if (BLOCKED && r0 < nr) ++kfetch;  // (behind the last step of the range: its own block once more)
+    pid = pid_next;
     FZ_FETCH_ROWS(pos);
     f1 = f2; r1 = r2;
     pos_next = pos_next2;
+    pid_next = r1 < nr ? FZ_FETCH_PID(f1) : 0;
     if (r2 < nr) FZ_ADVANCE(f2, r2);
-    pos_next2 = !BLOCKED && r2 < nr ? FZ_FETCH_POS(f2, FZ_LIM(r2)) : -1;
+    pos_next2 = r2 < nr ? FZ_FETCH_POS(f2, FZ_LIM(r2)) : -1;
     FZ_STAMP(5);  // fetches of the next step issued
 #include "ba_fused_step_b.inc"
     FZ_STAMP(6);  // matrix phase issued
@@ -264,6 +260,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
   }
   FZ_STAMP_FLUSH;
 #undef FZ_FETCH_POS
+#undef FZ_FETCH_PID
 #undef FZ_FETCH_ROWS
 #undef FZ_ADVANCE
 #undef FZ_LIM
@@ -387,8 +384,9 @@ __device__ __forceinline__ void fz_rows_from_state(RecT r2, PmT p2, double x0, d
 // a step and turned into its operands behind the panel stores, where k_fused_runs issues its gathers.
 template <int W, int T, int E, int WPS>
 __global__ __launch_bounds__(64, WPS) void k_fused_state(
-    const int32_t* __restrict__ rng_run, const int32_t* __restrict__ run_pt0, const int32_t* __restrict__ run_base,
-    const int32_t* __restrict__ slot_obs, const double* __restrict__ blk, const double* __restrict__ P,
+    const int32_t* __restrict__ rng_run, const int32_t* __restrict__ run_pt0, const int32_t* __restrict__ run_cam,
+    const int32_t* __restrict__ slot_obs, const int32_t* __restrict__ fz_pt, const double* __restrict__ blk,
+    const double* __restrict__ P,
     const double* __restrict__ X, const double* __restrict__ xt, double mu, double* __restrict__ Vinv,
     double* __restrict__ eps_b, double* __restrict__ part, int pmax, int n_pts, int m) {
   static_assert(16 * T + E >= 7 * W && 16 * T <= 7 * W + 15, "tiles and extra rows must cover the window");
@@ -425,37 +423,34 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
     }                                                                           \
   } while (0)
 #define FZ_LIM(r) __builtin_amdgcn_readfirstlane(bnd[(r) + 1])
-  // records and projection matrices of the window of run `rr` (relative to run0) into LDS; cameras
-  // past the last one read as the last (their slots hold no observation)
+  // records and projection matrices of the window of run `rr` (relative to run0) into LDS (the plan
+  // lists a camera for every slot: slots without one repeat the first, they hold no observation)
 #define FZ_LOAD_WINDOW(rr)                                                                         \
   do {                                                                                             \
-    const int base_ = __builtin_amdgcn_readfirstlane(run_base[run0 + (rr)]);                       \
+    const int32_t* wc_ = run_cam + 8 * (int64_t)(run0 + (rr));                                     \
     const double2* src_ = reinterpret_cast<const double2*>(blk);                                   \
     double2* dst_ = reinterpret_cast<double2*>(sRec);                                              \
     _Pragma("unroll") for (int i_ = 0; i_ < (8 * REC / 2 + 63) / 64; ++i_) {                       \
       const int e_ = lane + 64 * i_;                                                               \
       if (e_ < 8 * REC / 2) {                                                                      \
-        int c_ = base_ + e_ / (REC / 2);                                                           \
-        c_ = c_ < m ? c_ : m - 1;                                                                  \
+        const int c_ = wc_[e_ / (REC / 2)];                                                        \
         dst_[(e_ / (REC / 2)) * (RS / 2) + e_ % (REC / 2)] = src_[(int64_t)c_ * (REC / 2) + e_ % (REC / 2)]; \
       }                                                                                            \
     }                                                                                              \
     if (lane < 48) {                                                                               \
-      int c_ = base_ + lane / 6;                                                                   \
-      c_ = c_ < m ? c_ : m - 1;                                                                    \
+      const int c_ = wc_[lane / 6];                                                                \
       dst_[8 * RS / 2 + lane] = reinterpret_cast<const double2*>(P)[(int64_t)c_ * 6 + lane % 6];   \
     }                                                                                              \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                         \
     __builtin_amdgcn_wave_barrier();                                                               \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                         \
   } while (0)
-  // point and pixel of this lane's observation in the step that starts at `first` (lanes without one:
-  // the step's point all the same - it exists - and the first pixel)
-#define FZ_FETCH_STATE(first, pos_, X0, X1, X2, XT)                        \
+  // point (id pid_) and pixel of this lane's observation (lanes without one: the step's point all the
+  // same - it exists - and the first pixel)
+#define FZ_FETCH_PID(first) fz_pt[(unsigned)(((first) + p) < n_pts ? (first) + p : n_pts - 1)]
+#define FZ_FETCH_STATE(pid_, pos_, X0, X1, X2, XT)                         \
   do {                                                                     \
-    int pt_ = (first) + p;                                                 \
-    pt_ = pt_ < n_pts ? pt_ : n_pts - 1;                                   \
-    const double* xp_ = X + 3 * (int64_t)pt_;                              \
+    const double* xp_ = X + 3 * (int64_t)(pid_);                           \
     X0 = xp_[0];                                                           \
     X1 = xp_[1];                                                           \
     X2 = xp_[2];                                                           \
@@ -484,6 +479,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
   } while (0)
   const int pt_first = f0 + p < n_pts ? f0 + p : n_pts - 1;
   const int pos_raw = slot_obs[(unsigned)(kFzLanesPerPoint * pt_first + s)];
+  int pid = fz_pt[(unsigned)pt_first];
   for (int i = lane; i <= nr; i += 64) bnd[i] = run_pt0[run0 + i];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -496,14 +492,16 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
   FZ_RECORD_TO_REGS();
   double xn0, xn1, xn2;
   double2 xtn;
-  FZ_FETCH_STATE(f0, pos, xn0, xn1, xn2, xtn);
+  FZ_FETCH_STATE(pid, pos, xn0, xn1, xn2, xtn);
   FZ_ROWS(xn0, xn1, xn2, xtn, pos >= 0);
   int f1 = f0, r1 = r0;
   FZ_ADVANCE(f1, r1);
   int pos_next = r1 < nr ? FZ_FETCH_POS(f1, FZ_LIM(r1)) : -1;
+  int pid_next = r1 < nr ? FZ_FETCH_PID(f1) : 0;
   int f2 = f1, r2 = r1;
   if (r2 < nr) FZ_ADVANCE(f2, r2);
   int pos_next2 = r2 < nr ? FZ_FETCH_POS(f2, FZ_LIM(r2)) : -1;
+  int pid_next2 = r2 < nr ? FZ_FETCH_PID(f2) : 0;
 
   d4_t acc[NT];
 #pragma unroll
@@ -530,7 +528,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
     // the next step's point and pixel: on their way during this step's arithmetic (with two waves per
     // SIMD the five values would not fit into the registers across it: fetched where they are used,
     // and the other wave covers the wait)
-    if (WPS == 1 && r1 < nr) FZ_FETCH_STATE(f1, pos_next, xn0, xn1, xn2, xtn);
+    if (WPS == 1 && r1 < nr) FZ_FETCH_STATE(pid_next, pos_next, xn0, xn1, xn2, xtn);
     FZ_STAMP(1);
 #include "ba_fused_step_a.inc"
     FZ_STAMP(3);
@@ -540,8 +538,9 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     pos = pos_next;
+    pid = pid_next;
     if (r0 < nr) {
-      if (WPS != 1) FZ_FETCH_STATE(f0, pos, xn0, xn1, xn2, xtn);
+      if (WPS != 1) FZ_FETCH_STATE(pid, pos, xn0, xn1, xn2, xtn);
       if (r0 != r_win) {
         FZ_LOAD_WINDOW(r0);
         FZ_RECORD_TO_REGS();
@@ -551,8 +550,10 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
     }
     f1 = f2; r1 = r2;
     pos_next = pos_next2;
+    pid_next = pid_next2;
     if (r2 < nr) FZ_ADVANCE(f2, r2);
     pos_next2 = r2 < nr ? FZ_FETCH_POS(f2, FZ_LIM(r2)) : -1;
+    pid_next2 = r2 < nr ? FZ_FETCH_PID(f2) : 0;
     FZ_STAMP(5);
 #include "ba_fused_step_b.inc"
     FZ_STAMP(6);
@@ -561,6 +562,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
   }
   FZ_STAMP_FLUSH;
 #undef FZ_FETCH_POS
+#undef FZ_FETCH_PID
 #undef FZ_FETCH_STATE
 #undef FZ_ROWS
 #undef FZ_RECORD_TO_REGS
@@ -574,13 +576,13 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
 // Back-substitution straight from the state (src/sparse_ba.py:279-290 and the point update of
 // src/bundle_adjustment.py:100): delta_b_i = V_i^-1 (eps_b_i - sum_s B_s^T A_s delta_a[cam_s]) with the
 // rows of A formed in the kernel as in k_fused_state (B = minus the camera-centre columns of A).
-// One wave per range of points, a step of 8 points at a time; the window's camera records and its 56
+// One wave per range of positions, a step of 8 points at a time; the window's camera records and its 56
 // entries of delta_a sit in LDS.  X is read before it is updated: a point's rows depend on no other point.
 __global__ __launch_bounds__(64) void k_back_substitute_state(
-    const int32_t* __restrict__ rng_run, const int32_t* __restrict__ run_pt0, const int32_t* __restrict__ run_base,
-    const int32_t* __restrict__ slot_obs, const double* __restrict__ blk, const double* __restrict__ Vinv,
-    const double* __restrict__ eps_b, const double* __restrict__ da, double* __restrict__ db, double* __restrict__ X,
-    int update, double x_step, int pmax, int n_pts, int m) {
+    const int32_t* __restrict__ rng_run, const int32_t* __restrict__ run_pt0, const int32_t* __restrict__ run_cam,
+    const int32_t* __restrict__ slot_obs, const int32_t* __restrict__ fz_pt, const double* __restrict__ blk,
+    const double* __restrict__ Vinv, const double* __restrict__ eps_b, const double* __restrict__ da,
+    double* __restrict__ db, double* __restrict__ X, int update, double x_step) {
   constexpr int REC = SFM_BA_CAM_BLK;
   __shared__ __attribute__((aligned(16))) double sRec[8 * REC];
   __shared__ double sDa[56];
@@ -588,56 +590,55 @@ __global__ __launch_bounds__(64) void k_back_substitute_state(
   const int p = lane >> 3, s = lane & 7;
   const int run_first = rng_run[blockIdx.x], run_last = rng_run[blockIdx.x + 1];
   for (int run = run_first; run < run_last; ++run) {
-    const int base = __builtin_amdgcn_readfirstlane(run_base[run]);
     const int beg = __builtin_amdgcn_readfirstlane(run_pt0[run]), end = __builtin_amdgcn_readfirstlane(run_pt0[run + 1]);
     {
+      const int32_t* wc = run_cam + 8 * (int64_t)run;
       const double2* src = reinterpret_cast<const double2*>(blk);
       double2* dst = reinterpret_cast<double2*>(sRec);
 #pragma unroll
       for (int i = 0; i < (8 * REC / 2 + 63) / 64; ++i) {
         const int e = lane + 64 * i;
-        if (e < 8 * REC / 2) {
-          int c = base + e / (REC / 2);
-          c = c < m ? c : m - 1;
-          dst[e] = src[(int64_t)c * (REC / 2) + e % (REC / 2)];
-        }
+        if (e < 8 * REC / 2) dst[e] = src[(int64_t)wc[e / (REC / 2)] * (REC / 2) + e % (REC / 2)];
       }
-      if (lane < 56) {
-        int c = base + lane / 7;
-        c = c < m ? c : m - 1;
-        sDa[lane] = da[7 * (int64_t)c + lane % 7];
-      }
+      if (lane < 56) sDa[lane] = da[7 * (int64_t)wc[lane / 7] + lane % 7];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    // the table entry and the point of a step are fetched one step ahead, V^-1 and eps_b of the step at
-    // its top: nothing below waits for a load it has just issued
-    int pos_n;
+    // the point id of a step is fetched two steps ahead, its table entry and its point one step ahead, V^-1
+    // and eps_b of the step at its top: nothing below waits for a load it has just issued
+    int pos_n, pid_n, pid_n2;
     double xn0, xn1, xn2;
-#define FZ_BS_FETCH(first)                                                                \
+#define FZ_BS_PID(first) fz_pt[(unsigned)((first) + p < end ? (first) + p : end - 1)]
+#define FZ_BS_FETCH(first, pid_)                                                          \
   do {                                                                                    \
     const int ptn_ = (first) + p < end ? (first) + p : end - 1;                           \
     pos_n = (first) + p < end ? slot_obs[(unsigned)(kFzLanesPerPoint * ptn_ + s)] : -1;   \
-    const double* xq_ = X + 3 * (int64_t)ptn_;                                            \
+    const double* xq_ = X + 3 * (int64_t)(pid_);                                          \
     xn0 = xq_[0];                                                                         \
     xn1 = xq_[1];                                                                         \
     xn2 = xq_[2];                                                                         \
   } while (0)
-    FZ_BS_FETCH(beg);
+    pid_n = FZ_BS_PID(beg);
+    pid_n2 = FZ_BS_PID(beg + 8);
+    FZ_BS_FETCH(beg, pid_n);
     for (int f = beg; f < end; f += 8) {
-      const int pt = f + p;
-      const bool live = pt < end;
+      const bool live = f + p < end;
       const int pos = pos_n;
+      const int pid = pid_n;
       const double x0 = xn0, x1 = xn1, x2 = xn2;
-      if (f + 8 < end) FZ_BS_FETCH(f + 8);
+      pid_n = pid_n2;
+      if (f + 8 < end) {
+        FZ_BS_FETCH(f + 8, pid_n);
+        pid_n2 = FZ_BS_PID(f + 16);
+      }
       double vv[9], eb[3];
       if (s == 0 && live) {
-        const double* v = Vinv + 9 * (int64_t)pt;
+        const double* v = Vinv + 9 * (int64_t)pid;
 #pragma unroll
         for (int i = 0; i < 9; ++i) vv[i] = v[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) eb[i] = eps_b[3 * (int64_t)pt + i];
+        for (int i = 0; i < 3; ++i) eb[i] = eps_b[3 * (int64_t)pid + i];
       }
       double2 av[9];
       fz_rows_from_state<false>(reinterpret_cast<const double2*>(sRec + REC * s), static_cast<const double2*>(nullptr), x0,
@@ -659,67 +660,67 @@ __global__ __launch_bounds__(64) void k_back_substitute_state(
         const double d0 = vv[0] * r0 + vv[1] * r1 + vv[2] * r2;
         const double d1 = vv[3] * r0 + vv[4] * r1 + vv[5] * r2;
         const double d2 = vv[6] * r0 + vv[7] * r1 + vv[8] * r2;
-        db[3 * (int64_t)pt] = d0; db[3 * (int64_t)pt + 1] = d1; db[3 * (int64_t)pt + 2] = d2;
+        db[3 * (int64_t)pid] = d0; db[3 * (int64_t)pid + 1] = d1; db[3 * (int64_t)pid + 2] = d2;
         if (update) {
-          X[3 * (int64_t)pt] = x0 + x_step * d0;
-          X[3 * (int64_t)pt + 1] = x1 + x_step * d1;
-          X[3 * (int64_t)pt + 2] = x2 + x_step * d2;
+          X[3 * (int64_t)pid] = x0 + x_step * d0;
+          X[3 * (int64_t)pid + 1] = x1 + x_step * d1;
+          X[3 * (int64_t)pid + 2] = x2 + x_step * d2;
         }
       }
     }
 #undef FZ_BS_FETCH
+#undef FZ_BS_PID
     // the next run's window overwrites the records: every lane is done reading them
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
 }
 
-// partial results of the runs of one window, added in run order
-__global__ __launch_bounds__(256) void k_fused_reduce(const int32_t* __restrict__ key_ptr,
-                                                      const int32_t* __restrict__ key_run, int64_t stride,
+// partial results of the runs of one window (they are consecutive), added in run order
+__global__ __launch_bounds__(256) void k_fused_reduce(const int32_t* __restrict__ key_run, int64_t stride,
                                                       const double* __restrict__ part, double* __restrict__ kpart) {
   const int key = blockIdx.x;
-  const int beg = key_ptr[key], end = key_ptr[key + 1];
-  if (beg == end) return;
+  const int beg = key_run[key], end = key_run[key + 1];
   for (int64_t el = (int64_t)blockIdx.y * 256 + threadIdx.x; el < stride; el += (int64_t)gridDim.y * 256) {
     double sum = 0.0;
     int i = beg;
     for (; i + 4 <= end; i += 4) {
-      const double v0 = part[(int64_t)key_run[i] * stride + el];
-      const double v1 = part[(int64_t)key_run[i + 1] * stride + el];
-      const double v2 = part[(int64_t)key_run[i + 2] * stride + el];
-      const double v3 = part[(int64_t)key_run[i + 3] * stride + el];
+      const double v0 = part[(int64_t)i * stride + el];
+      const double v1 = part[(int64_t)(i + 1) * stride + el];
+      const double v2 = part[(int64_t)(i + 2) * stride + el];
+      const double v3 = part[(int64_t)(i + 3) * stride + el];
       sum = (((sum + v0) + v1) + v2) + v3;
     }
-    for (; i < end; ++i) sum += part[(int64_t)key_run[i] * stride + el];
+    for (; i < end; ++i) sum += part[(int64_t)i * stride + el];
     kpart[(int64_t)key * stride + el] = sum;
   }
 }
 
 // one 64-lane workgroup per camera pair (j <= k) that shares a point: add the windows that hold both
-// cameras, write the block of S below the diagonal (diagonal blocks in full, with U_j and the
-// damping), and for diagonal blocks e_j
+// cameras (the plan lists them with the cameras' slots, ascending) and then the partial results the far
+// plan's camera-pair kernel left for the pair, write the block of S below the diagonal (diagonal blocks
+// in full, with U_j and the damping), and for diagonal blocks e_j
 __global__ __launch_bounds__(64) void k_fused_finish(const int32_t* __restrict__ blk_j, const int32_t* __restrict__ blk_k,
-                                                     const int32_t* __restrict__ key_ptr, int slots, int group,
-                                                     const double* __restrict__ kpart, double mu_u, int m,
-                                                     double* __restrict__ S, double* __restrict__ e_out) {
+                                                     const int32_t* __restrict__ fb_ptr, const int32_t* __restrict__ fb_ent,
+                                                     const int32_t* __restrict__ fb_far_part,
+                                                     const int32_t* __restrict__ fb_far_cnt, int slots,
+                                                     const double* __restrict__ kpart, const double* __restrict__ far_part,
+                                                     double mu_u, int m, double* __restrict__ S, double* __restrict__ e_out) {
   const int t = threadIdx.x;
   const int j = blk_j[blockIdx.x], k = blk_k[blockIdx.x];
   if (t >= 56 || (t >= 49 && j != k)) return;
   const int T = fz_row_tiles(slots), E = fz_extra_rows(slots);
   const int nt = T * (T + 1) / 2;
   const int64_t stride = fz_part_stride_c(T, E);
-  const int lo = k - slots + 1 > 0 ? k - slots + 1 : 0;
-  const int key_lo = (lo + group - 1) / group, key_hi = j / group;
   const int r = t / 7, c = t - 7 * r;
   const int ulo = r < c ? r : c, uhi = r < c ? c : r;
   const int uidx = ulo * 7 - ulo * (ulo - 1) / 2 + (uhi - ulo);
   double sum = 0.0;
-  for (int key = key_lo; key <= key_hi; ++key) {
-    if (key_ptr[key + 1] == key_ptr[key]) continue;
-    const int base = key * group;
-    const int sj = j - base, sk = k - base;
-    const double* pb = kpart + (int64_t)key * stride;
+  const int e_end = fb_ptr[blockIdx.x + 1];
+  for (int en = fb_ptr[blockIdx.x]; en < e_end; ++en) {
+    const int ent = fb_ent[en];
+    const int sj = (ent >> 3) & 7, sk = ent & 7;
+    const double* pb = kpart + (int64_t)(ent >> 6) * stride;
     if (t < 49) {
       // (Y_j W_k^T)[r][c] = D[7 sk + c][7 sj + r]; D is symmetric and its lower triangle is stored
       // (a diagonal block takes both of its triangles from the lower one)
@@ -742,6 +743,15 @@ __global__ __launch_bounds__(64) void k_fused_finish(const int32_t* __restrict__
       sum += pb[nt * 256 + (28 + (t - 49)) * 8 + sj];
     }
   }
+  // the far points' share: sum A_j^T T A_k over their entries of the pair, which on the diagonal holds
+  // sum Y W^T - U_j (see k_point), and sum A^T g in slots 49..55 of a diagonal block's partials
+  {
+    const int cnt = fb_far_cnt[blockIdx.x];
+    const double* fp = far_part + (int64_t)fb_far_part[blockIdx.x] * kPairPartStride + t;
+    double far = 0.0;
+    for (int i = 0; i < cnt; ++i) far += fp[(int64_t)i * kPairPartStride];
+    if (cnt > 0) sum = (t >= 49 || j != k) ? sum + far : sum - far;
+  }
   const int64_t ld = 7 * (int64_t)m;
   if (t >= 49) {
     S[ld * ld + 7 * j + (t - 49)] = sum;
@@ -753,62 +763,42 @@ __global__ __launch_bounds__(64) void k_fused_finish(const int32_t* __restrict__
   }
 }
 
-// Back-substitution on the step blocks (src/sparse_ba.py:279-290): lane (p, s) of a step holds the
-// row of A of point p's observation by the window's camera s (zeros for none);
-// delta_b_i = V_i^-1 (eps_b_i - sum_s B_s^T A_s delta_a[cam_s]) with B = minus the camera-centre columns of A.
-__global__ __launch_bounds__(256) void k_back_substitute_steps(
-    int n_steps, const int32_t* __restrict__ step_pt0, const int32_t* __restrict__ step_run,
-    const int32_t* __restrict__ run_pt0, const int32_t* __restrict__ run_base, const double2* __restrict__ Ab,
-    const double* __restrict__ Vinv, const double* __restrict__ eps_b, const double* __restrict__ da,
-    double* __restrict__ db, double* __restrict__ Xupd, double x_step, int m) {
-  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (k >= n_steps) return;
-  const int lane = threadIdx.x & 63, p = lane >> 3, s = lane & 7;
-  const int run = step_run[k];
-  const int pt = step_pt0[k] + p, lim = run_pt0[run + 1];
-  int cam = run_base[run] + s;
-  cam = cam < m ? cam : m - 1;  // (a slot past the last camera holds no observation: its row is zero)
-  const double2* bp = Ab + (int64_t)k * 512 + lane;
-  double a[14];
-#pragma unroll
-  for (int q = 0; q < 7; ++q) {
-    const double2 v = bp[64 * q];
-    a[2 * q] = v.x;
-    a[2 * q + 1] = v.y;
+// Far points of a plan whose far points have no observation at all (ids nobody names, allowed on plans
+// built with size hints; with observations among them the far plan's kernels do this): V_i = mu I,
+// eps_b_i = 0 (src/sparse_ba.py:201-212, 163-171 with an empty sum), and delta_b_i = 0.
+__global__ void k_far_unobserved(const int32_t* __restrict__ far_pt, int n_far, double mu, double* __restrict__ Vinv,
+                                 double* __restrict__ eps_b, double* __restrict__ db) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_far) return;
+  const int64_t i = far_pt[q];
+  if (Vinv) {
+    const double d = 1.0 / mu;
+    double* v = Vinv + 9 * i;
+    v[0] = d; v[1] = 0; v[2] = 0; v[3] = 0; v[4] = d; v[5] = 0; v[6] = 0; v[7] = 0; v[8] = d;
+    eps_b[3 * i] = 0; eps_b[3 * i + 1] = 0; eps_b[3 * i + 2] = 0;
   }
-  // delta_a of the window's 8 cameras (56 contiguous doubles) through LDS: one load per lane
-  __shared__ double sDa[4][56];
-  {
-    const int base = run_base[run];
-    const int nd = (m - base < 8 ? m - base : 8) * 7;
-    if (lane < nd) sDa[threadIdx.x >> 6][lane] = da[7 * (int64_t)base + lane];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (db) {
+    db[3 * i] = 0; db[3 * i + 1] = 0; db[3 * i + 2] = 0;
   }
-  const double* dj = sDa[threadIdx.x >> 6] + 7 * (cam - run_base[run]);
-  double h0 = 0.0, h1 = 0.0;
-#pragma unroll
-  for (int q = 0; q < 7; ++q) {
-    h0 += a[q] * dj[q];
-    h1 += a[7 + q] * dj[q];
-  }
-  const double c0 = sum8(-a[4] * h0 - a[11] * h1);
-  const double c1 = sum8(-a[5] * h0 - a[12] * h1);
-  const double c2 = sum8(-a[6] * h0 - a[13] * h1);
-  if (s == 0 && pt < lim) {
-    const double r0 = eps_b[3 * (int64_t)pt] - c0, r1 = eps_b[3 * (int64_t)pt + 1] - c1,
-                 r2 = eps_b[3 * (int64_t)pt + 2] - c2;
-    const double* v = Vinv + 9 * (int64_t)pt;
-    const double d0 = v[0] * r0 + v[1] * r1 + v[2] * r2;
-    const double d1 = v[3] * r0 + v[4] * r1 + v[5] * r2;
-    const double d2 = v[6] * r0 + v[7] * r1 + v[8] * r2;
-    db[3 * (int64_t)pt] = d0; db[3 * (int64_t)pt + 1] = d1; db[3 * (int64_t)pt + 2] = d2;
-    if (Xupd) {
-      Xupd[3 * (int64_t)pt] += x_step * d0;
-      Xupd[3 * (int64_t)pt + 1] += x_step * d1;
-      Xupd[3 * (int64_t)pt + 2] += x_step * d2;
-    }
+}
+
+// rows of A, observed and predicted pixels of the far observations, gathered into the far plan's order
+__global__ __launch_bounds__(256) void k_far_gather(const int32_t* __restrict__ far_obs, int64_t nf,
+                                                    const double* __restrict__ A, const double* __restrict__ xt,
+                                                    const double* __restrict__ xp, double* __restrict__ A_far,
+                                                    double* __restrict__ xt_far, double* __restrict__ xp_far) {
+  // 9 pieces of 16 bytes per observation: 7 of the row of A, x_true, x_pred
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= 9 * nf) return;
+  const int64_t i = g / 9;
+  const int q = (int)(g - 9 * i);
+  const int64_t o = far_obs[i];
+  if (q < 7) {
+    if (A) *reinterpret_cast<double2*>(A_far + 14 * i + 2 * q) = ldg2(A + 14 * o + 2 * q);
+  } else if (q == 7) {
+    *reinterpret_cast<double2*>(xt_far + 2 * i) = ldg2(xt + 2 * o);
+  } else if (xp) {
+    *reinterpret_cast<double2*>(xp_far + 2 * i) = ldg2(xp + 2 * o);
   }
 }
 
@@ -833,10 +823,31 @@ static void fz_print_stamps() {
 #endif
 // reduce and finish shared by the two kernels that produce the partial results
 static int launch_fused_tail(const sfm_ba_plan* p, double mu_u, double* S, double* e, double* part, double* kpart,
-                             hipStream_t st);
+                             const double* far_part, hipStream_t st);
 
 bool fz_state_applies(const sfm_ba_plan* p) {
   return p->n_runs > 0 && p->fz_enabled && p->fz_max_range_runs <= kFzMaxRunsPerRange;
+}
+
+// The far points' share of the assembly: V^-1, eps_b of those points, g and T in the far plan's
+// workspace, and the partial results of its camera-pair blocks, which k_fused_finish adds into S.
+// A_far, xt_far, xp_far: rows of A and pixels in the far plan's observation order.
+static int launch_far_unobserved(const sfm_ba_plan* p, double mu, double* Vinv, double* eps_b, double* db,
+                                 hipStream_t st) {
+  if (p->far || p->n_far <= 0) return SFM_BA_OK;
+  hipLaunchKernelGGL(k_far_unobserved, dim3((p->n_far + 255) / 256), dim3(256), 0, st, p->d_far_pt, p->n_far, mu, Vinv,
+                     eps_b, db);
+  return check_launch_fz("k_far_unobserved");
+}
+
+static int launch_far_assemble(const sfm_ba_plan* p, const double* A_far, const double* xt_far, const double* xp_far,
+                               double mu, double* Vinv, double* eps_b, char* ws, hipStream_t st) {
+  if (!p->far) return SFM_BA_OK;
+  return launch_assemble_parts(p->far, p->d_far_pt, A_far, xt_far, xp_far, mu, Vinv, eps_b, ws + p->ws_far, st);
+}
+
+static const double* far_partials(const sfm_ba_plan* p, const char* ws) {
+  return p->far ? reinterpret_cast<const double*>(ws + p->ws_far + p->far->ws_spart) : nullptr;
 }
 
 int launch_assemble_state(const sfm_ba_plan* p, const double* blk, const double* P, const double* X, const double* xt,
@@ -846,6 +857,25 @@ int launch_assemble_state(const sfm_ba_plan* p, const double* blk, const double*
   char* base = static_cast<char*>(ws);
   double* part = reinterpret_cast<double*>(base + p->ws_fpart);
   double* kpart = reinterpret_cast<double*>(base + p->ws_fkey);
+  if (p->far) {
+    // far points: their rows of A and predictions from the state (the Jacobian kernel on the far plan's
+    // observation list), their observed pixels gathered beside them
+    double* A_far = reinterpret_cast<double*>(base + p->ws_far_A);
+    double* xt_far = reinterpret_cast<double*>(base + p->ws_far_xt);
+    double* xp_far = reinterpret_cast<double*>(base + p->ws_far_xp);
+    int rc = launch_jacobian(blk, P, X, p->d_far_cam, p->d_far_gpt, p->n_far_obs, A_far, nullptr, xp_far, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_far_gather, dim3((unsigned)((9 * p->n_far_obs + 255) / 256)), dim3(256), 0, st, p->d_far_obs,
+                       p->n_far_obs, static_cast<const double*>(nullptr), xt, static_cast<const double*>(nullptr), A_far,
+                       xt_far, xp_far);
+    rc = check_launch_fz("k_far_gather");
+    if (rc) return rc;
+    rc = launch_far_assemble(p, A_far, xt_far, xp_far, mu, Vinv, eps_b, base, st);
+    if (rc) return rc;
+  } else {
+    const int rc = launch_far_unobserved(p, mu, Vinv, eps_b, nullptr, st);
+    if (rc) return rc;
+  }
   {
     ProfScope ps(KID_FUSED_STATE, st);
     // waves per SIMD: with windows of up to six cameras the kernel fits 256 registers (what it spills
@@ -861,10 +891,12 @@ int launch_assemble_state(const sfm_ba_plan* p, const double* blk, const double*
   do {                                                                                                                  \
     if (wps_state == 2)                                                                                                 \
       hipLaunchKernelGGL((k_fused_state<W, T, E, 2>), dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0,   \
-                         p->d_run_base, p->d_slot_obs, blk, P, X, xt, mu, Vinv, eps_b, part, p->fz_pmax, p->n, p->m);   \
+                         p->d_run_cam, p->d_slot_obs, p->d_fz_pt, blk, P, X, xt, mu, Vinv, eps_b, part, p->fz_pmax,     \
+                         p->n_near, p->m);                                                                              \
     else                                                                                                                \
       hipLaunchKernelGGL((k_fused_state<W, T, E, 1>), dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0,   \
-                         p->d_run_base, p->d_slot_obs, blk, P, X, xt, mu, Vinv, eps_b, part, p->fz_pmax, p->n, p->m);   \
+                         p->d_run_cam, p->d_slot_obs, p->d_fz_pt, blk, P, X, xt, mu, Vinv, eps_b, part, p->fz_pmax,     \
+                         p->n_near, p->m);                                                                              \
   } while (0)
     switch (p->fz_slots) {
       case 4: FZ_LAUNCH_STATE(4, 2, 0); break;
@@ -881,49 +913,60 @@ int launch_assemble_state(const sfm_ba_plan* p, const double* blk, const double*
   const int rc = check_launch_fz("k_fused_state");
   if (rc) return rc;
   if (!S) return SFM_BA_OK;
-  return launch_fused_tail(p, mu_u, S, e, part, kpart, st);
+  return launch_fused_tail(p, mu_u, S, e, part, kpart, far_partials(p, base), st);
 }
 
 int launch_back_substitute_state(const sfm_ba_plan* p, const double* blk, const double* Vinv, const double* eps_b,
-                                 const double* da, double* db, double* X, int update, double x_step, hipStream_t st) {
+                                 const double* da, double* db, double* X, int update, double x_step, void* ws,
+                                 hipStream_t st) {
   if (p->n_runs <= 0) return SFM_BA_EINVAL;
-  ProfScope ps(KID_BACK_STATE, st);
-  hipLaunchKernelGGL(k_back_substitute_state, dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0, p->d_run_base,
-                     p->d_slot_obs, blk, Vinv, eps_b, da, db, X, update, x_step, p->fz_pmax, p->n, p->m);
-  return check_launch_fz("k_back_substitute_state");
+  {
+    ProfScope ps(KID_BACK_STATE, st);
+    hipLaunchKernelGGL(k_back_substitute_state, dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0,
+                       p->d_run_cam, p->d_slot_obs, p->d_fz_pt, blk, Vinv, eps_b, da, db, X, update, x_step);
+  }
+  const int rc = check_launch_fz("k_back_substitute_state");
+  if (rc) return rc;
+  if (!p->far) return launch_far_unobserved(p, 1.0, nullptr, nullptr, db, st);
+  // far points: from the rows the assembly left in the workspace
+  const double* A_far = reinterpret_cast<const double*>(static_cast<char*>(ws) + p->ws_far_A);
+  return launch_back_substitute_mapped(p->far, p->d_far_pt, A_far, Vinv, eps_b, da, db, update ? X : nullptr, x_step, st);
 }
 
-int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* xt, const double* xp,
-                          const double* steps, double mu, double mu_u, double* S, double* e, double* Vinv,
-                          double* eps_b, void* ws, hipStream_t st) {
+int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* xt, const double* xp, double mu,
+                          double mu_u, double* S, double* e, double* Vinv, double* eps_b, void* ws, hipStream_t st) {
   if (p->n_runs <= 0) return SFM_BA_OK;
   char* base = static_cast<char*>(ws);
   double* part = reinterpret_cast<double*>(base + p->ws_fpart);
   double* kpart = reinterpret_cast<double*>(base + p->ws_fkey);
+  if (p->far) {
+    double* A_far = reinterpret_cast<double*>(base + p->ws_far_A);
+    double* xt_far = reinterpret_cast<double*>(base + p->ws_far_xt);
+    double* xp_far = reinterpret_cast<double*>(base + p->ws_far_xp);
+    hipLaunchKernelGGL(k_far_gather, dim3((unsigned)((9 * p->n_far_obs + 255) / 256)), dim3(256), 0, st, p->d_far_obs,
+                       p->n_far_obs, A, xt, xp, A_far, xt_far, xp_far);
+    int rc = check_launch_fz("k_far_gather");
+    if (rc) return rc;
+    rc = launch_far_assemble(p, A_far, xt_far, xp_far, mu, Vinv, eps_b, base, st);
+    if (rc) return rc;
+  } else {
+    const int rc = launch_far_unobserved(p, mu, Vinv, eps_b, nullptr, st);
+    if (rc) return rc;
+  }
   {
     ProfScope ps(KID_FUSED_RUNS, st);
-#define FZ_LAUNCH4(W, T, E, WPS, BL)                                                                             \
-  hipLaunchKernelGGL((k_fused_runs<W, T, E, WPS, BL>), dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0, \
-                     p->d_slot_obs, A, xt, xp, p->d_rng_step, reinterpret_cast<const double2*>(steps), mu, Vinv,    \
-                     eps_b, part, p->fz_pmax, p->n)
-#define FZ_LAUNCH(W, T, E)                    \
-  do {                                        \
-    if (steps) {                              \
-      if (wps == 1)                           \
-        FZ_LAUNCH4(W, T, E, 1, true);         \
-      else                                    \
-        FZ_LAUNCH4(W, T, E, 2, true);         \
-    } else {                                  \
-      if (wps == 1)                           \
-        FZ_LAUNCH4(W, T, E, 1, false);        \
-      else                                    \
-        FZ_LAUNCH4(W, T, E, 2, false);        \
-    }                                         \
+#define FZ_LAUNCH4(W, T, E, WPS)                                                                                    \
+  hipLaunchKernelGGL((k_fused_runs<W, T, E, WPS>), dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0, \
+                     p->d_slot_obs, p->d_fz_pt, A, xt, xp, mu, Vinv, eps_b, part, p->fz_pmax, p->n_near)
+#define FZ_LAUNCH(W, T, E)          \
+  do {                              \
+    if (wps == 1)                   \
+      FZ_LAUNCH4(W, T, E, 1);       \
+    else                            \
+      FZ_LAUNCH4(W, T, E, 2);       \
   } while (0)
     // waves per SIMD the kernel is compiled for: two (256 registers each) hide memory latency better,
-    // unless the variant then spills - a reload from scratch memory waits for every load in flight.
-    // The 5-slot variant (three rows behind the tiles: 21 more accumulators) spills at 256 registers
-    // and runs 2.3 x faster with 512 (1 800 cameras x 1 M points: 319 us against 737 us).
+    // unless the variant then spills - a reload from scratch memory waits for every load in flight
     static const int wps_env = [] {
       const char* v = getenv("SFM_BA_FZ_WPS");
       return v && (v[0] == '1' || v[0] == '2') ? v[0] - '0' : 0;
@@ -945,37 +988,24 @@ int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* x
   int rc = check_launch_fz("k_fused_runs");
   if (rc) return rc;
   if (!S) return SFM_BA_OK;
-  return launch_fused_tail(p, mu_u, S, e, part, kpart, st);
+  return launch_fused_tail(p, mu_u, S, e, part, kpart, far_partials(p, base), st);
 }
 
 static int launch_fused_tail(const sfm_ba_plan* p, double mu_u, double* S, double* e, double* part, double* kpart,
-                             hipStream_t st) {
+                             const double* far_part, hipStream_t st) {
   const int64_t stride = fz_part_stride(p->fz_slots);
   {
     ProfScope ps(KID_FUSED_REDUCE, st);
-    hipLaunchKernelGGL(k_fused_reduce, dim3(p->n_keys, 3), dim3(256), 0, st, p->d_key_ptr, p->d_key_run, stride, part,
-                       kpart);
+    hipLaunchKernelGGL(k_fused_reduce, dim3(p->n_keys, 3), dim3(256), 0, st, p->d_key_run, stride, part, kpart);
   }
   int rc = check_launch_fz("k_fused_reduce");
   if (rc) return rc;
   if (p->n_blocks > 0) {
     ProfScope ps(KID_FUSED_FINISH, st);
-    hipLaunchKernelGGL(k_fused_finish, dim3(p->n_blocks), dim3(64), 0, st, p->d_blk_j, p->d_blk_k, p->d_key_ptr,
-                       p->fz_slots, p->fz_group, kpart, mu_u, p->m, S, e);
+    hipLaunchKernelGGL(k_fused_finish, dim3(p->n_blocks), dim3(64), 0, st, p->d_blk_j, p->d_blk_k, p->d_fb_ptr,
+                       p->d_fb_ent, p->d_fb_far_part, p->d_fb_far_cnt, p->fz_slots, kpart, far_part, mu_u, p->m, S, e);
   }
   return check_launch_fz("k_fused_finish");
-}
-
-int launch_back_substitute_steps(const sfm_ba_plan* p, const double* steps, const double* Vinv, const double* eps_b,
-                                 const double* da, double* db, double* Xupd, double x_step, hipStream_t st) {
-  if (p->n_steps <= 0) return SFM_BA_OK;
-  {
-    ProfScope ps(KID_BACK, st);
-    hipLaunchKernelGGL(k_back_substitute_steps, dim3((p->n_steps + 3) / 4), dim3(256), 0, st, p->n_steps, p->d_step_pt0,
-                       p->d_step_run, p->d_run_pt0, p->d_run_base, reinterpret_cast<const double2*>(steps), Vinv, eps_b,
-                       da, db, Xupd, x_step, p->m);
-  }
-  return check_launch_fz("k_back_substitute_steps");
 }
 
 }  // namespace sfmba

@@ -257,67 +257,6 @@ __global__ __launch_bounds__(256) void k_jacobian(
   }
 }
 
-// The same Jacobian rows and the residual, written as step blocks for the fused assembly and the
-// back-substitution on steps: block k (8 KiB) = step k of the plan, piece q (1 KiB) = 16 bytes per
-// lane (p, s) = (point of the step, camera slot of the run's window): pieces 0..6 the row of A
-// ([dF/dQ | dF/dC] of the x pixel, then of the y pixel), piece 7 x_true - x_pred; zeros where the
-// point has no observation by that camera.  Every store is a whole contiguous KiB.
-__global__ __launch_bounds__(256) void k_jacobian_steps(
-    int n_steps, const int32_t* __restrict__ step_pt0, const int32_t* __restrict__ step_run,
-    const int32_t* __restrict__ run_pt0, const int32_t* __restrict__ run_base,
-    const int32_t* __restrict__ slot_obs, const double* __restrict__ blk, const double* __restrict__ P,
-    const double* __restrict__ X, const double* __restrict__ xt, double2* __restrict__ Ab, int m) {
-  // per wave: the prepared records (56 doubles) and projection matrices (12) of the 8 cameras of the
-  // step's window, copied once from their contiguous range; the lanes then read their camera's from LDS
-  __shared__ __attribute__((aligned(16))) double sRec[4][8 * (SFM_BA_CAM_BLK + 12)];
-  const int wave = threadIdx.x >> 6;
-  const int k = blockIdx.x * 4 + wave;
-  if (k >= n_steps) return;
-  const int lane = threadIdx.x & 63, p = lane >> 3, s = lane & 7;
-  const int run = step_run[k];
-  const int base = run_base[run];
-  const int pt = step_pt0[k] + p;
-  const int pos = pt < run_pt0[run + 1] ? slot_obs[kFzLanesPerPoint * (int64_t)pt + s] : -1;
-  double* rec = sRec[wave];
-  {
-    const int ncam = m - base < 8 ? m - base : 8;  // cameras of the window that exist
-    const double2* src = reinterpret_cast<const double2*>(blk + (int64_t)SFM_BA_CAM_BLK * base);
-    double2* dst = reinterpret_cast<double2*>(rec);
-    for (int i = lane; i < ncam * (SFM_BA_CAM_BLK / 2); i += 64) dst[i] = src[i];
-    const double2* srcp = reinterpret_cast<const double2*>(P + 12 * (int64_t)base);
-    double2* dstp = reinterpret_cast<double2*>(rec + 8 * SFM_BA_CAM_BLK);
-    for (int i = lane; i < ncam * 6; i += 64) dstp[i] = srcp[i];
-  }
-  // one wave wrote and reads: its LDS operations complete in order
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  double2 out[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) out[q] = make_double2(0.0, 0.0);
-  if (pos >= 0) {
-    const double x0 = X[3 * (int64_t)pt], x1 = X[3 * (int64_t)pt + 1], x2 = X[3 * (int64_t)pt + 2];
-    JacOut o;
-    jacobian_rows(rec + SFM_BA_CAM_BLK * s, x0, x1, x2, o);
-    const double* pm = rec + 8 * SFM_BA_CAM_BLK + 12 * s;
-    const double h0 = pm[0] * x0 + pm[1] * x1 + pm[2] * x2 + pm[3];
-    const double h1 = pm[4] * x0 + pm[5] * x1 + pm[6] * x2 + pm[7];
-    const double h2 = pm[8] * x0 + pm[9] * x1 + pm[10] * x2 + pm[11];
-    const double2 xo = ld2(xt + 2 * (int64_t)pos);
-    out[0] = make_double2(o.a0[0], o.a0[1]);
-    out[1] = make_double2(o.a0[2], o.a0[3]);
-    out[2] = make_double2(-o.b0[0], -o.b0[1]);
-    out[3] = make_double2(-o.b0[2], o.a1[0]);
-    out[4] = make_double2(o.a1[1], o.a1[2]);
-    out[5] = make_double2(o.a1[3], -o.b1[0]);
-    out[6] = make_double2(-o.b1[1], -o.b1[2]);
-    out[7] = make_double2(xo.x - h0 / h2, xo.y - h1 / h2);
-  }
-  double2* bp = Ab + (int64_t)k * 512 + lane;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) bp[64 * q] = out[q];
-}
-
 // One Jacobi rotation of a symmetric 3 x 3 matrix that annihilates a_pq; r is the third index.
 // vp, vq: the matching columns of the accumulated rotations.
 __device__ inline void jacobi_rot3(double& app, double& aqq, double& apq, double& arp, double& arq,
@@ -423,7 +362,7 @@ __device__ inline void point_inverse(const double* a, double mu, double (&inv)[6
 // A point with more observations than a workgroup has lanes (its range holds this point alone):
 // the lanes stride over the observations twice - sums for V_i and eps_b_i, reduced through LDS in a
 // fixed order, then g and the k (k + 1) / 2 couplings, the second observation's terms re-read.
-__device__ __noinline__ void point_long(int t, int p0, int s0, int ns, const int32_t* __restrict__ perm,
+__device__ __noinline__ void point_long(int t, int p0, int pid, int s0, int ns, const int32_t* __restrict__ perm,
                                         const int32_t* __restrict__ tp_ptr, const int32_t* __restrict__ pair_entry,
                                         const double* __restrict__ A, const double* __restrict__ B,
                                         const double* __restrict__ xt, const double* __restrict__ xpred,
@@ -463,11 +402,11 @@ __device__ __noinline__ void point_long(int t, int p0, int s0, int ns, const int
   const double z1 = iv[1] * a[6] + iv[3] * a[7] + iv[4] * a[8];
   const double z2 = iv[2] * a[6] + iv[4] * a[7] + iv[5] * a[8];
   if (t == 0) {
-    double* vo = Vinv + 9 * (int64_t)p0;
+    double* vo = Vinv + 9 * (int64_t)pid;
     vo[0] = iv[0]; vo[1] = iv[1]; vo[2] = iv[2];
     vo[3] = iv[1]; vo[4] = iv[3]; vo[5] = iv[4];
     vo[6] = iv[2]; vo[7] = iv[4]; vo[8] = iv[5];
-    double* eo = eps_b + 3 * (int64_t)p0;
+    double* eo = eps_b + 3 * (int64_t)pid;
     eo[0] = a[6]; eo[1] = a[7]; eo[2] = a[8];
   }
   const int64_t k = ns;
@@ -507,10 +446,11 @@ __device__ __noinline__ void point_long(int t, int p0, int s0, int ns, const int
 // per-point stage: V_i, V_i^-1, eps_b_i, then per observation g = w (eps - B V^-1 eps_b) and per
 // observation pair (a <= b) of the point the 2x2 coupling T_ab = (wB)_a V^-1 (wB)_b^T.
 // One workgroup owns a run of points with at most kGroupSlots observations; one lane per
-// observation, then one lane per point.
+// observation, then one lane per point.  pt_map (may be null): id under which point p of the plan
+// keeps its V^-1 and eps_b (the far plan of a larger plan numbers its points from 0).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_point(
-    const int32_t* __restrict__ grp_pt, const int32_t* __restrict__ pt_ptr,
+    const int32_t* __restrict__ pt_map, const int32_t* __restrict__ grp_pt, const int32_t* __restrict__ pt_ptr,
     const int32_t* __restrict__ perm, const int32_t* __restrict__ tp_ptr,
     const int32_t* __restrict__ pair_entry, const double* __restrict__ A,
     const double* __restrict__ B, const double* __restrict__ xt, const double* __restrict__ xpred,
@@ -528,7 +468,8 @@ __global__ __launch_bounds__(256) void k_point(
   const int s0 = sPtr[0];
   const int ns = sPtr[np] - s0;
   if (ns > kGroupSlots) {  // one point with more observations than lanes (same for the whole workgroup)
-    point_long(t, p0, s0, ns, perm, tp_ptr, pair_entry, A, B, xt, xpred, wgt, mu, fold_u, Vinv, eps_b, g, T, sCon);
+    point_long(t, p0, pt_map ? pt_map[p0] : p0, s0, ns, perm, tp_ptr, pair_entry, A, B, xt, xpred, wgt, mu, fold_u, Vinv,
+               eps_b, g, T, sCon);
     return;
   }
   if (t < np)
@@ -597,11 +538,12 @@ __global__ __launch_bounds__(256) void k_point(
       vz[7] = i01 * a[6] + i11 * a[7] + i12 * a[8];
       vz[8] = i02 * a[6] + i12 * a[7] + i22 * a[8];
     }
-    double* vo = Vinv + 9 * (int64_t)(p0 + t);
+    const int pid = pt_map ? pt_map[p0 + t] : p0 + t;
+    double* vo = Vinv + 9 * (int64_t)pid;
     vo[0] = i00; vo[1] = i01; vo[2] = i02;
     vo[3] = i01; vo[4] = i11; vo[5] = i12;
     vo[6] = i02; vo[7] = i12; vo[8] = i22;
-    double* eo = eps_b + 3 * (int64_t)(p0 + t);
+    double* eo = eps_b + 3 * (int64_t)pid;
     eo[0] = a[6]; eo[1] = a[7]; eo[2] = a[8];
   }
   __syncthreads();
@@ -1091,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_lower_unpack(const double* __restrict__
 // back-substitution: delta_b_i = V_i^-1 (eps_b_i - sum_a B_a^T w_a A_a delta_a[cam_a])
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_back_substitute(
-    const int32_t* __restrict__ grp_pt, const int32_t* __restrict__ pt_ptr,
+    const int32_t* __restrict__ pt_map, const int32_t* __restrict__ grp_pt, const int32_t* __restrict__ pt_ptr,
     const int32_t* __restrict__ perm, const int32_t* __restrict__ slot_cam,
     const double* __restrict__ A, const double* __restrict__ B, const double* __restrict__ wgt,
     const double* __restrict__ Vinv, const double* __restrict__ eps_b, const double* __restrict__ da,
@@ -1146,7 +1088,7 @@ __global__ __launch_bounds__(256) void k_back_substitute(
       __syncthreads();
     }
     if (t == 0) {
-      const int64_t p = p0;
+      const int64_t p = pt_map ? pt_map[p0] : p0;
       const double r0 = eps_b[3 * p] - sV[0], r1 = eps_b[3 * p + 1] - sV[1], r2 = eps_b[3 * p + 2] - sV[2];
       const double* v = Vinv + 9 * p;
       const double d0 = v[0] * r0 + v[1] * r1 + v[2] * r2;
@@ -1195,7 +1137,7 @@ __global__ __launch_bounds__(256) void k_back_substitute(
       a1 += sV[3 * s + 1];
       a2 += sV[3 * s + 2];
     }
-    const int64_t p = p0 + t;
+    const int64_t p = pt_map ? pt_map[p0 + t] : p0 + t;
     const double r0 = eps_b[3 * p] - a0, r1 = eps_b[3 * p + 1] - a1, r2 = eps_b[3 * p + 2] - a2;
     const double* v = Vinv + 9 * p;
     const double d0 = v[0] * r0 + v[1] * r1 + v[2] * r2;
@@ -1397,18 +1339,6 @@ int launch_jacobian(const double* blk, const double* P, const double* X, const i
   return check_launch("k_jacobian");
 }
 
-int launch_jacobian_steps(const sfm_ba_plan* p, const double* blk, const double* P, const double* X, const double* xt,
-                          double* steps, hipStream_t st) {
-  if (p->n_steps <= 0) return SFM_BA_OK;
-  {
-    ProfScope ps(KID_JACOBIAN, st);
-    hipLaunchKernelGGL(k_jacobian_steps, dim3((p->n_steps + 3) / 4), dim3(256), 0, st, p->n_steps, p->d_step_pt0,
-                       p->d_step_run, p->d_run_pt0, p->d_run_base, p->d_slot_obs, blk, P, X, xt,
-                       reinterpret_cast<double2*>(steps), p->m);
-  }
-  return check_launch("k_jacobian_steps");
-}
-
 int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, const double* xt,
                     const double* xp, const double* w, double mu, double mu_u, double* S, double* e,
                     double* U, double* eps_a, double* Vinv, double* eps_b, double* cam_red,
@@ -1424,12 +1354,12 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
   // ... and, where the plan found runs of points inside narrow camera windows, the whole assembly
   // is one pass over A (ba_fused.hip).  That path takes the point block from A and needs mu > 0.
   if (fold_u && !B && !w && mu > 0.0 && p->n_runs > 0 && p->fz_enabled)
-    return launch_assemble_fused(p, A, xt, xp, nullptr, mu, mu_u, S, e, Vinv, eps_b, ws, st);
+    return launch_assemble_fused(p, A, xt, xp, mu, mu_u, S, e, Vinv, eps_b, ws, st);
   if (p->n_groups > 0) {
     {
     ProfScope ps(KID_POINT, st);
-    hipLaunchKernelGGL(k_point, dim3(p->n_groups), dim3(256), 0, st, p->d_grp_pt, p->d_pt_ptr, p->d_perm,
-                       p->d_tp_ptr, p->d_pair_entry, A, B, xt, xp, w, mu, fold_u, Vinv, eps_b, g, T);
+    hipLaunchKernelGGL(k_point, dim3(p->n_groups), dim3(256), 0, st, static_cast<const int32_t*>(nullptr), p->d_grp_pt,
+                       p->d_pt_ptr, p->d_perm, p->d_tp_ptr, p->d_pair_entry, A, B, xt, xp, w, mu, fold_u, Vinv, eps_b, g, T);
   }
     int rc = check_launch("k_point");
     if (rc) return rc;
@@ -1473,6 +1403,40 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
       rc = check_launch("k_pair_finish");
       if (rc) return rc;
     }
+  }
+  return SFM_BA_OK;
+}
+
+// The camera-pair path for the far plan of a larger plan (every block of such a plan keeps partial
+// results): V^-1 and eps_b of its points under the ids pt_map gives them, and per block the partial sums
+// of A_j^T T A_k - which on the diagonal hold sum Y W^T - U_j - and of A^T g, left in the workspace for the
+// finishing kernel of the larger plan.  The point block is taken from A; no weights.
+int launch_assemble_parts(const sfm_ba_plan* p, const int32_t* pt_map, const double* A, const double* xt,
+                          const double* xp, double mu, double* Vinv, double* eps_b, void* ws, hipStream_t st) {
+  if (!p->force_parts) return SFM_BA_EINVAL;
+  char* base = static_cast<char*>(ws);
+  double* g = reinterpret_cast<double*>(base + p->ws_g);
+  double* T = reinterpret_cast<double*>(base + p->ws_T);
+  double* spart = reinterpret_cast<double*>(base + p->ws_spart);
+  if (p->n_groups > 0) {
+    {
+      ProfScope ps(KID_POINT, st);
+      hipLaunchKernelGGL(k_point, dim3(p->n_groups), dim3(256), 0, st, pt_map, p->d_grp_pt, p->d_pt_ptr, p->d_perm,
+                         p->d_tp_ptr, p->d_pair_entry, A, static_cast<const double*>(nullptr), xt, xp,
+                         static_cast<const double*>(nullptr), mu, 1, Vinv, eps_b, g, T);
+    }
+    const int rc = check_launch("k_point");
+    if (rc) return rc;
+  }
+  if (p->n_pair_items > 0) {
+    {
+      ProfScope ps(KID_PAIR_BLOCKS, st);
+      hipLaunchKernelGGL(k_pair_blocks, dim3(p->n_pair_items), dim3(64), 0, st, p->n_pair_items, p->d_pit_blk, p->d_pit_beg,
+                         p->d_pit_end, p->d_pit_part, p->d_blk_j, p->d_blk_k, p->d_entries, A, g,
+                         (unsigned)(p->ws_T - p->ws_g), 1, static_cast<const double*>(nullptr), p->d_cam_item_ptr, 0.0,
+                         p->m, static_cast<double*>(nullptr), static_cast<double*>(nullptr), spart);
+    }
+    return check_launch("k_pair_blocks");
   }
   return SFM_BA_OK;
 }
@@ -1537,8 +1501,22 @@ int launch_back_substitute(const sfm_ba_plan* p, const double* A, const double* 
   if (p->n_groups <= 0) return SFM_BA_OK;
   {
     ProfScope ps(KID_BACK, st);
-    hipLaunchKernelGGL(k_back_substitute, dim3(p->n_groups), dim3(256), 0, st, p->d_grp_pt, p->d_pt_ptr,
-                     p->d_perm, p->d_slot_cam, A, B, w, Vinv, eps_b, da, db, Xupd, x_step);
+    hipLaunchKernelGGL(k_back_substitute, dim3(p->n_groups), dim3(256), 0, st, static_cast<const int32_t*>(nullptr),
+                       p->d_grp_pt, p->d_pt_ptr, p->d_perm, p->d_slot_cam, A, B, w, Vinv, eps_b, da, db, Xupd, x_step);
+  }
+  return check_launch("k_back_substitute");
+}
+
+// the same for the far plan of a larger plan: point p of the plan is point pt_map[p] of Vinv, eps_b, db, Xupd
+int launch_back_substitute_mapped(const sfm_ba_plan* p, const int32_t* pt_map, const double* A, const double* Vinv,
+                                  const double* eps_b, const double* da, double* db, double* Xupd, double x_step,
+                                  hipStream_t st) {
+  if (p->n_groups <= 0) return SFM_BA_OK;
+  {
+    ProfScope ps(KID_BACK, st);
+    hipLaunchKernelGGL(k_back_substitute, dim3(p->n_groups), dim3(256), 0, st, pt_map, p->d_grp_pt, p->d_pt_ptr, p->d_perm,
+                       p->d_slot_cam, A, static_cast<const double*>(nullptr), static_cast<const double*>(nullptr), Vinv,
+                       eps_b, da, db, Xupd, x_step);
   }
   return check_launch("k_back_substitute");
 }

@@ -48,6 +48,16 @@ void plan_set_workspace(sfm_ba_plan* p) {
   off = align256(off + (int64_t)p->n_keys * fz_part_stride(p->fz_slots) * (int64_t)sizeof(double));
   p->ws_fzero = off;  // a row of zeros
   off = align256(off + 256);
+  // far points: their rows of A, observed and predicted pixels in the far plan's observation order,
+  // then that plan's own workspace
+  p->ws_far_A = off;
+  off = align256(off + p->n_far_obs * 14 * (int64_t)sizeof(double));
+  p->ws_far_xt = off;
+  off = align256(off + p->n_far_obs * 2 * (int64_t)sizeof(double));
+  p->ws_far_xp = off;
+  off = align256(off + p->n_far_obs * 2 * (int64_t)sizeof(double));
+  p->ws_far = off;
+  off = align256(off + (p->far ? p->far->ws_total : 0));
   p->ws_total = off;
 }
 
@@ -62,15 +72,24 @@ extern "C" void sfm_ba_plan_destroy(sfm_ba_plan* p) {
   void* ptrs[] = {p->d_pt_ptr,   p->d_perm,     p->d_slot_cam, p->d_tp_ptr,  p->d_grp_pt,  p->d_cam_obs, p->d_pair_entry,
                   p->d_item_cam, p->d_item_beg, p->d_item_end, p->d_cam_item_ptr, p->d_blk_j, p->d_blk_k,
                   p->d_entries,  p->d_pit_blk,  p->d_pit_beg,  p->d_pit_end, p->d_pit_part, p->d_mb_blk,
-                  p->d_mb_part,  p->d_mb_cnt,   p->d_run_pt0,  p->d_run_base, p->d_slot_obs, p->d_key_ptr,
-                  p->d_key_run,  p->d_rng_run,  p->d_step_pt0, p->d_step_run, p->d_rng_step};
+                  p->d_mb_part,  p->d_mb_cnt,   p->d_fz_pt,    p->d_slot_obs, p->d_run_pt0, p->d_run_key,
+                  p->d_run_cam,  p->d_rng_run,  p->d_key_cam,  p->d_key_run, p->d_fb_ptr,  p->d_fb_ent,
+                  p->d_fb_far_part, p->d_fb_far_cnt, p->d_far_pt, p->d_far_obs, p->d_far_cam, p->d_far_lpt, p->d_far_gpt};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
+  sfm_ba_plan_destroy(p->far);
   delete p;
 }
 
-extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx, int64_t N, int32_t m_hint,
-                                  int32_t n_hint, int check, sfm_ba_plan** out) {
+namespace {
+enum PlanFlags { kPlanNoFused = 1, kPlanForceParts = 2 };
+// what the builder of a plan with far points needs to know of the far plan's blocks
+struct HostBlocks {
+  std::vector<int32_t> blk_j, blk_k, mb_part, mb_cnt;
+};
+
+int build_host(const int32_t* cam_idx, const int32_t* pt_idx, int64_t N, int32_t m_hint, int32_t n_hint, int check,
+               int flags, HostBlocks* blocks_out, sfm_ba_plan** out) {
   if (!out) return SFM_BA_EINVAL;
   *out = nullptr;
   if (!cam_idx || !pt_idx || N <= 0 || N >= (int64_t(1) << 31)) return SFM_BA_EINVAL;
@@ -119,13 +138,14 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
     }
   }
   int32_t kshort = 0;  // kshort: the most views among the points that fit one workgroup range
+  bool nonunique = false;
   for (int32_t i = 0; i < n; ++i) {
     const int32_t k = pt_ptr[i + 1] - pt_ptr[i];
     if (k <= kGroupSlots) kshort = std::max(kshort, k);
-    if (check)
-      for (int32_t s = pt_ptr[i] + 1; s < pt_ptr[i + 1]; ++s)
-        if (slot_cam[s] == slot_cam[s - 1]) return SFM_BA_ENONUNIQUE;
+    for (int32_t s = pt_ptr[i] + 1; s < pt_ptr[i + 1]; ++s)
+      if (slot_cam[s] == slot_cam[s - 1]) nonunique = true;
   }
+  if (check && nonunique) return SFM_BA_ENONUNIQUE;
   if (N * 112 >= (int64_t(1) << 32)) return SFM_BA_ETOOBIG;  // 32-bit byte offsets into A
 
   sfm_ba_plan* p = new (std::nothrow) sfm_ba_plan();
@@ -133,6 +153,7 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   p->m = m;
   p->n = n;
   p->n_obs = N;
+  p->force_parts = (flags & kPlanForceParts) ? 1 : 0;
 
   // ---- per-point pair slots and workgroup ranges ----
   // A point takes max(k, 1) units; it opens a new workgroup range when its first unit falls into
@@ -233,7 +254,8 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   for (int32_t b = 0; b < p->n_blocks; ++b) {
     const int32_t beg = blk_ptr[b], end = blk_ptr[b + 1];
     const int32_t chunks = (end - beg + kPairChunk - 1) / kPairChunk;
-    if (chunks > 1) {
+    const bool parts = chunks > 1 || p->force_parts;  // (a far plan's blocks are all finished by the plan above it)
+    if (parts) {
       mb_blk.push_back(b);
       mb_part.push_back(n_parts);
       mb_cnt.push_back(chunks);
@@ -242,84 +264,161 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
       pit_blk.push_back(b);
       pit_beg.push_back(beg + c * kPairChunk);
       pit_end.push_back(std::min(beg + (c + 1) * kPairChunk, end));
-      pit_part.push_back(chunks > 1 ? n_parts++ : -1);
+      pit_part.push_back(parts ? n_parts++ : -1);
     }
   }
   p->n_pair_items = (int32_t)pit_blk.size();
   p->n_parts = n_parts;
   p->n_multi = (int32_t)mb_blk.size();
 
-  // ---- runs of the fused point-major assembly ----
-  // Every point's cameras must fit a window of 6 or 8 consecutive ids.  `group` consecutive
-  // first-cameras share a window (key = first camera / group, base camera = key * group); a run is
-  // a maximal range of consecutive points with one key, cut at multiples of pmax.  The rule needs
-  // no sequential pass either.
-  std::vector<int32_t> run_pt0, run_base, slot_obs, key_ptr, key_run, rng_run, step_pt0, step_run, rng_step;
-  {
-    int32_t span_max = 0;
+  if (blocks_out) {
+    blocks_out->blk_j = blk_j;
+    blocks_out->blk_k = blk_k;
+    blocks_out->mb_part = mb_part;
+    blocks_out->mb_cnt = mb_cnt;
+  }
+
+  // ---- near points of the fused point-major assembly, far points (same rules as the device builder) ----
+  std::vector<int32_t> fz_pt, slot_obs, run_pt0, run_key, run_cam, rng_run, key_cam, key_run, fb_ptr, fb_ent, fb_far_part,
+      fb_far_cnt, far_pt, far_obs, far_cam, far_lpt, far_gpt;
+  // (a list that names a (camera, point) pair twice - accepted only without checks - stays on the
+  // camera-pair path, which adds both; the slot table of the fused path has room for one)
+  if (!(flags & kPlanNoFused) && !nonunique) {
+    int64_t obs_by_k[9] = {0}, obs_by_span[9] = {0};
     bool empty_point = false;
     for (int32_t i = 0; i < n; ++i) {
-      if (pt_ptr[i + 1] == pt_ptr[i]) {
-        empty_point = true;
-        continue;
-      }
-      span_max = std::max(span_max, slot_cam[pt_ptr[i + 1] - 1] - slot_cam[pt_ptr[i]] + 1);
+      const int32_t k = pt_ptr[i + 1] - pt_ptr[i];
+      if (k == 0) empty_point = true;
+      if (k < 1 || k > 8) continue;
+      obs_by_k[k] += k;
+      const int32_t span = slot_cam[pt_ptr[i + 1] - 1] - slot_cam[pt_ptr[i]] + 1;
+      if (span <= 8) obs_by_span[span] += k;
     }
-    FzShape sh;
-    if (fz_shape(n, span_max, empty_point, &sh)) {
-      int32_t prev_key = -1;
-      for (int32_t i = 0; i < n; ++i) {
-        const int32_t key = slot_cam[pt_ptr[i]] / sh.group;
-        if (i == 0 || key != prev_key || i % sh.pmax == 0) {
-          run_pt0.push_back(i);
-          run_base.push_back(key * sh.group);
-        }
-        prev_key = key;
+    const int slots = fz_choose_slots(obs_by_k, obs_by_span);
+    std::vector<int32_t> desc, cand, near;
+    std::vector<uint64_t> key;
+    if (slots > 0) {
+      desc.assign((size_t)n * 8, -1);
+      key.assign((size_t)n, 0);
+      for (int32_t i = 0; i < n; ++i)
+        if (fz_point_window(slot_cam.data() + pt_ptr[i], pt_ptr[i + 1] - pt_ptr[i], slots, m, &desc[(size_t)8 * i], &key[i]))
+          cand.push_back(i);
+      std::stable_sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+    }
+    auto same_window = [&](int32_t a, int32_t b) {
+      return memcmp(&desc[(size_t)8 * a], &desc[(size_t)8 * b], 8 * sizeof(int32_t)) == 0;
+    };
+    // windows = maximal stretches of equal camera lists in the sorted order; short ones are given up
+    for (size_t q = 0; q < cand.size();) {
+      size_t r = q + 1;
+      while (r < cand.size() && same_window(cand[q], cand[r])) ++r;
+      if (r - q >= (size_t)kFzMinWindowPoints) near.insert(near.end(), cand.begin() + q, cand.begin() + r);
+      q = r;
+    }
+    const int32_t n_near = (int32_t)near.size();
+    const int32_t pmax = fz_pmax_for(n_near);
+    for (int32_t q = 0; q < n_near; ++q) {
+      const bool new_window = q == 0 || !same_window(near[q], near[q - 1]);
+      if (new_window) {
+        key_run.push_back((int32_t)run_pt0.size());
+        key_cam.insert(key_cam.end(), &desc[(size_t)8 * near[q]], &desc[(size_t)8 * near[q]] + 8);
       }
-      const int32_t n_runs = (int32_t)run_pt0.size();
-      run_pt0.push_back(n);
-      if (fz_worthwhile(n, n_runs)) {
-        p->fz_slots = sh.slots;
-        p->fz_group = sh.group;
-        p->fz_pmax = sh.pmax;
-        p->n_runs = n_runs;
-        p->n_keys = (m - 1) / sh.group + 1;
-        // a run starts at every multiple of pmax: ranges of pmax points own whole runs
-        p->n_ranges = (n + sh.pmax - 1) / sh.pmax;
-        rng_run.assign(p->n_ranges + 1, n_runs);
-        for (int32_t r = n_runs - 1; r >= 0; --r)
-          if (run_pt0[r] % sh.pmax == 0) rng_run[run_pt0[r] / sh.pmax] = r;
-        for (int32_t g = 0; g < p->n_ranges; ++g)
-          p->fz_max_range_runs = std::max(p->fz_max_range_runs, rng_run[g + 1] - rng_run[g]);
-        // steps of 8 points, run by run
-        std::vector<int32_t> run_step0(n_runs + 1, 0);
-        for (int32_t r = 0; r < n_runs; ++r) {
-          run_step0[r] = (int32_t)step_pt0.size();
-          for (int32_t f = run_pt0[r]; f < run_pt0[r + 1]; f += 8) {
-            step_pt0.push_back(f);
-            step_run.push_back(r);
+      if (new_window || q % pmax == 0) {
+        run_pt0.push_back(q);
+        run_key.push_back((int32_t)key_run.size() - 1);
+        const int32_t* d = &desc[(size_t)8 * near[q]];
+        for (int s = 0; s < 8; ++s) run_cam.push_back(d[s] >= 0 ? d[s] : d[0]);
+      }
+    }
+    const int32_t n_runs = (int32_t)run_pt0.size();
+    int64_t n_far_obs = N;
+    for (int32_t q = 0; q < n_near; ++q) n_far_obs -= pt_ptr[near[q] + 1] - pt_ptr[near[q]];
+    // (points without observations - allowed on plans built with size hints - go with the far points)
+    (void)empty_point;
+    (void)n_far_obs;
+    if (fz_worthwhile(n, n_near, n_runs)) {
+      p->fz_slots = slots;
+      p->fz_pmax = pmax;
+      p->n_near = n_near;
+      p->n_runs = n_runs;
+      p->n_keys = (int32_t)key_run.size();
+      key_run.push_back(n_runs);
+      run_pt0.push_back(n_near);
+      p->n_ranges = (n_near + pmax - 1) / pmax;
+      rng_run.assign(p->n_ranges + 1, n_runs);
+      for (int32_t r = n_runs - 1; r >= 0; --r)
+        if (run_pt0[r] % pmax == 0) rng_run[run_pt0[r] / pmax] = r;
+      for (int32_t g = 0; g < p->n_ranges; ++g)
+        p->fz_max_range_runs = std::max(p->fz_max_range_runs, rng_run[g + 1] - rng_run[g]);
+      for (int32_t r = 0; r < n_runs; ++r) p->n_steps += (run_pt0[r + 1] - run_pt0[r] + 7) / 8;
+      fz_pt = near;
+      std::vector<int32_t> pos_of((size_t)n, -1);
+      for (int32_t q = 0; q < n_near; ++q) pos_of[near[q]] = q;
+      slot_obs.assign((size_t)n_near * kFzLanesPerPoint, -1);
+      for (int32_t q = 0; q < n_near; ++q) {
+        const int32_t i = near[q];
+        for (int32_t s = pt_ptr[i]; s < pt_ptr[i + 1]; ++s)
+          slot_obs[(size_t)q * kFzLanesPerPoint + fz_slot_of(&desc[(size_t)8 * i], slot_cam[s])] = perm[s];
+      }
+      // far points and their observations
+      std::vector<int32_t> far_num((size_t)n, -1);
+      for (int32_t i = 0; i < n; ++i)
+        if (pos_of[i] < 0) {
+          far_num[i] = (int32_t)far_pt.size();
+          far_pt.push_back(i);
+        }
+      for (int64_t o = 0; o < N; ++o)
+        if (far_num[pt_idx[o]] >= 0) {
+          far_obs.push_back((int32_t)o);
+          far_cam.push_back(cam_idx[o]);
+          far_lpt.push_back(far_num[pt_idx[o]]);
+          far_gpt.push_back(pt_idx[o]);
+        }
+      p->n_far = (int32_t)far_pt.size();
+      p->n_far_obs = (int64_t)far_obs.size();
+      HostBlocks fb;
+      if (p->n_far_obs > 0) {
+        const int rc_far = build_host(far_cam.data(), far_lpt.data(), p->n_far_obs, m, p->n_far, 0,
+                                      kPlanNoFused | kPlanForceParts, &fb, &p->far);
+        if (rc_far != SFM_BA_OK) {
+          sfm_ba_plan_destroy(p);
+          return rc_far;
+        }
+      }
+      // what the finishing kernel adds up for every block: the windows that hold both cameras (ascending),
+      // then the far plan's partial results
+      std::vector<int32_t> blk_of((size_t)m * m, -1);
+      for (int32_t b = 0; b < p->n_blocks; ++b) blk_of[(size_t)blk_j[b] * m + blk_k[b]] = b;
+      fb_ptr.assign((size_t)p->n_blocks + 1, 0);
+      for (int pass = 0; pass < 2; ++pass) {
+        std::vector<int32_t> fill(fb_ptr.begin(), fb_ptr.end() - 1);
+        for (int32_t q = 0; q < p->n_keys; ++q)
+          for (int a = 0; a < 8; ++a) {
+            const int32_t ca = key_cam[(size_t)8 * q + a];
+            if (ca < 0) continue;
+            for (int b = a; b < 8; ++b) {
+              const int32_t cb = key_cam[(size_t)8 * q + b];
+              if (cb < 0) continue;
+              const int32_t id = blk_of[(size_t)ca * m + cb];
+              if (id < 0) continue;
+              if (pass == 0)
+                ++fb_ptr[(size_t)id + 1];
+              else
+                fb_ent[(size_t)fill[id]++] = (q << 6) | (a << 3) | b;
+            }
           }
+        if (pass == 0) {
+          for (int32_t b = 0; b < p->n_blocks; ++b) fb_ptr[(size_t)b + 1] += fb_ptr[b];
+          fb_ent.resize((size_t)fb_ptr[p->n_blocks]);
         }
-        run_step0[n_runs] = (int32_t)step_pt0.size();
-        p->n_steps = (int32_t)step_pt0.size();
-        step_run.push_back(n_runs);
-        rng_step.resize(p->n_ranges + 1);
-        for (int32_t g = 0; g <= p->n_ranges; ++g) rng_step[g] = run_step0[rng_run[g]];
-        slot_obs.assign((size_t)n * kFzLanesPerPoint, -1);
-        for (int32_t i = 0; i < n; ++i) {
-          const int32_t base = slot_cam[pt_ptr[i]] / sh.group * sh.group;
-          for (int32_t s = pt_ptr[i]; s < pt_ptr[i + 1]; ++s)
-            slot_obs[(size_t)i * kFzLanesPerPoint + (slot_cam[s] - base)] = perm[s];
-        }
-        key_ptr.assign(p->n_keys + 1, 0);
-        for (int32_t r = 0; r < n_runs; ++r) ++key_ptr[run_base[r] / sh.group + 1];
-        for (int32_t q = 0; q < p->n_keys; ++q) key_ptr[q + 1] += key_ptr[q];
-        key_run.resize(n_runs);
-        std::vector<int32_t> fill(key_ptr.begin(), key_ptr.end() - 1);
-        for (int32_t r = 0; r < n_runs; ++r) key_run[fill[run_base[r] / sh.group]++] = r;
-      } else {
-        run_pt0.clear();
-        run_base.clear();
+      }
+      p->n_fb = (int32_t)fb_ent.size();
+      fb_far_part.assign((size_t)p->n_blocks, -1);
+      fb_far_cnt.assign((size_t)p->n_blocks, 0);
+      for (size_t q = 0; q < fb.blk_j.size(); ++q) {
+        const int32_t id = blk_of[(size_t)fb.blk_j[q] * m + fb.blk_k[q]];  // a far block is a block of the whole
+        fb_far_part[id] = fb.mb_part[q];
+        fb_far_cnt[id] = fb.mb_cnt[q];
       }
     }
   }
@@ -352,15 +451,23 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   up(mb_part, &p->d_mb_part);
   up(mb_cnt, &p->d_mb_cnt);
   if (p->n_runs > 0) {
-    up(run_pt0, &p->d_run_pt0);
-    up(run_base, &p->d_run_base);
+    up(fz_pt, &p->d_fz_pt);
     up(slot_obs, &p->d_slot_obs);
-    up(key_ptr, &p->d_key_ptr);
-    up(key_run, &p->d_key_run);
+    up(run_pt0, &p->d_run_pt0);
+    up(run_key, &p->d_run_key);
+    up(run_cam, &p->d_run_cam);
     up(rng_run, &p->d_rng_run);
-    up(step_pt0, &p->d_step_pt0);
-    up(step_run, &p->d_step_run);
-    up(rng_step, &p->d_rng_step);
+    up(key_cam, &p->d_key_cam);
+    up(key_run, &p->d_key_run);
+    up(fb_ptr, &p->d_fb_ptr);
+    up(fb_ent, &p->d_fb_ent);
+    up(fb_far_part, &p->d_fb_far_part);
+    up(fb_far_cnt, &p->d_fb_far_cnt);
+    up(far_pt, &p->d_far_pt);
+    up(far_obs, &p->d_far_obs);
+    up(far_cam, &p->d_far_cam);
+    up(far_lpt, &p->d_far_lpt);
+    up(far_gpt, &p->d_far_gpt);
   }
   if (rc != SFM_BA_OK) {
     sfm_ba_plan_destroy(p);
@@ -372,6 +479,14 @@ extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx,
   *out = p;
   return SFM_BA_OK;
 }
+}  // namespace
+
+extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx, int64_t N, int32_t m_hint,
+                                  int32_t n_hint, int check, sfm_ba_plan** out) {
+  return build_host(cam_idx, pt_idx, N, m_hint, n_hint, check, 0, nullptr, out);
+}
+
+extern "C" const sfm_ba_plan* sfm_ba_plan_far(const sfm_ba_plan* p) { return p ? p->far : nullptr; }
 
 extern "C" int sfm_ba_plan_sizes(const sfm_ba_plan* p, int64_t what[8]) {
   if (!p || !what) return SFM_BA_EINVAL;
@@ -413,14 +528,22 @@ extern "C" int sfm_ba_plan_read(const sfm_ba_plan* p, int field, void* h_dst, in
     case 19: src = p->d_mb_part; count = p->n_multi; break;
     case 20: src = p->d_mb_cnt; count = p->n_multi; break;
     case 21: src = p->d_run_pt0; count = p->n_runs > 0 ? p->n_runs + 1 : 0; break;
-    case 22: src = p->d_run_base; count = p->n_runs; break;
-    case 23: src = p->d_slot_obs; count = p->n_runs > 0 ? (int64_t)p->n * kFzLanesPerPoint : 0; break;
-    case 24: src = p->d_key_ptr; count = p->n_runs > 0 ? p->n_keys + 1 : 0; break;
-    case 25: src = p->d_key_run; count = p->n_runs; break;
+    case 22: src = p->d_run_key; count = p->n_runs; break;
+    case 23: src = p->d_slot_obs; count = (int64_t)p->n_near * kFzLanesPerPoint; break;
+    case 24: src = p->d_key_cam; count = (int64_t)p->n_keys * 8; break;
+    case 25: src = p->d_key_run; count = p->n_runs > 0 ? p->n_keys + 1 : 0; break;
     case 26: src = p->d_rng_run; count = p->n_runs > 0 ? p->n_ranges + 1 : 0; break;
-    case 27: src = p->d_step_pt0; count = p->n_steps; break;
-    case 28: src = p->d_step_run; count = p->n_runs > 0 ? p->n_steps + 1 : 0; break;
-    case 29: src = p->d_rng_step; count = p->n_runs > 0 ? p->n_ranges + 1 : 0; break;
+    case 27: src = p->d_fz_pt; count = p->n_near; break;
+    case 28: src = p->d_run_cam; count = (int64_t)p->n_runs * 8; break;
+    case 29: src = p->d_fb_ptr; count = p->n_runs > 0 ? p->n_blocks + 1 : 0; break;
+    case 30: src = p->d_fb_ent; count = p->n_fb; break;
+    case 31: src = p->d_fb_far_part; count = p->n_runs > 0 ? p->n_blocks : 0; break;
+    case 32: src = p->d_fb_far_cnt; count = p->n_runs > 0 ? p->n_blocks : 0; break;
+    case 33: src = p->d_far_pt; count = p->n_far; break;
+    case 34: src = p->d_far_obs; count = p->n_far_obs; break;
+    case 35: src = p->d_far_cam; count = p->n_far_obs; break;
+    case 36: src = p->d_far_lpt; count = p->n_far_obs; break;
+    case 37: src = p->d_far_gpt; count = p->n_far_obs; break;
     default: return SFM_BA_EINVAL;
   }
   *bytes_out = count * width;
@@ -440,7 +563,7 @@ extern "C" int sfm_ba_plan_fused_info(const sfm_ba_plan* p, int32_t info[8]) {
   if (!p || !info) return SFM_BA_EINVAL;
   info[0] = p->n_runs > 0 && p->fz_enabled ? 1 : 0;
   info[1] = p->fz_slots;
-  info[2] = p->fz_group;
+  info[2] = p->n_near;
   info[3] = p->fz_pmax;
   info[4] = p->n_runs;
   info[5] = p->n_keys;

@@ -40,7 +40,7 @@ struct Scratch {
 // statistics the host reads back between phases
 enum Stat {
   ST_MAX_CAM = 0, ST_MAX_PT, ST_NEGATIVE, ST_CAM_UNSORTED, ST_KMAX, ST_EMPTY_CAM, ST_EMPTY_PT, ST_NONUNIQUE,
-  ST_MAX_DIST, ST_SPAN_MAX, ST_KSHORT, ST_COUNT
+  ST_MAX_DIST, ST_KSHORT, ST_N_CAND, ST_COUNT
 };
 
 __global__ void k_idx_stats(const int32_t* __restrict__ cam, const int32_t* __restrict__ pt, int64_t N,
@@ -240,19 +240,21 @@ __global__ void k_block_starts(const uint32_t* __restrict__ key, int64_t E, int3
 }
 
 // per block: work items (chunks of kPairChunk entries), whether it is split, its partial results
-__global__ void k_block_chunks(const int32_t* __restrict__ blk_ptr, int32_t nb, int32_t* __restrict__ chunks,
+// (force: every block keeps partial results - the far plan of a larger plan)
+__global__ void k_block_chunks(const int32_t* __restrict__ blk_ptr, int32_t nb, int force, int32_t* __restrict__ chunks,
                                int32_t* __restrict__ multi, int32_t* __restrict__ parts) {
   const int32_t b = blockIdx.x * kT + threadIdx.x;
   if (b > nb) return;
   const int32_t ch = b < nb ? (blk_ptr[b + 1] - blk_ptr[b] + kPairChunk - 1) / kPairChunk : 0;
+  const bool with_parts = ch > 1 || (force && ch > 0);
   chunks[b] = ch;
-  multi[b] = ch > 1 ? 1 : 0;
-  parts[b] = ch > 1 ? ch : 0;
+  multi[b] = with_parts ? 1 : 0;
+  parts[b] = with_parts ? ch : 0;
 }
 
 __global__ void k_pair_items_fill(const int32_t* __restrict__ blk_ptr, const int32_t* __restrict__ item_off,
                                   const int32_t* __restrict__ multi_off, const int32_t* __restrict__ part_off, int32_t nb,
-                                  int32_t* __restrict__ pit_blk, int32_t* __restrict__ pit_beg,
+                                  int force, int32_t* __restrict__ pit_blk, int32_t* __restrict__ pit_beg,
                                   int32_t* __restrict__ pit_end, int32_t* __restrict__ pit_part,
                                   int32_t* __restrict__ mb_blk, int32_t* __restrict__ mb_part,
                                   int32_t* __restrict__ mb_cnt) {
@@ -265,9 +267,9 @@ __global__ void k_pair_items_fill(const int32_t* __restrict__ blk_ptr, const int
     pit_blk[it0 + c] = b;
     pit_beg[it0 + c] = beg + c * kPairChunk;
     pit_end[it0 + c] = min(beg + (c + 1) * kPairChunk, end);
-    pit_part[it0 + c] = ch > 1 ? p0 + c : -1;
+    pit_part[it0 + c] = (ch > 1 || force) ? p0 + c : -1;
   }
-  if (ch > 1) {
+  if (ch > 1 || force) {
     const int32_t q = multi_off[b];
     mb_blk[q] = b;
     mb_part[q] = p0;
@@ -275,104 +277,235 @@ __global__ void k_pair_items_fill(const int32_t* __restrict__ blk_ptr, const int
   }
 }
 
-// widest range of camera ids seen by one point (cameras ascend inside a point's slots)
-__global__ void k_point_span(const int32_t* __restrict__ pt_ptr, const int32_t* __restrict__ slot_cam, int32_t n,
-                             int32_t* __restrict__ stats) {
+// ---- near / far points and the runs of the fused assembly (the rules of ba_common.h, as the host builder applies them) ----
+// observations of the points with v cameras / a camera span of v, v <= 8
+__global__ void k_fz_hist(const int32_t* __restrict__ pt_ptr, const int32_t* __restrict__ slot_cam, int32_t n,
+                          unsigned long long* __restrict__ hist) {
+  __shared__ unsigned long long sh[18];
+  if (threadIdx.x < 18) sh[threadIdx.x] = 0;
+  __syncthreads();
   const int32_t i = blockIdx.x * kT + threadIdx.x;
-  if (i >= n) return;
-  const int32_t b = pt_ptr[i], e = pt_ptr[i + 1];
-  if (e > b) atomicMax(&stats[ST_SPAN_MAX], slot_cam[e - 1] - slot_cam[b] + 1);
-}
-
-// runs of the fused assembly: a point opens a run when its window key (first camera / group)
-// differs from its predecessor's or its id is a multiple of pmax
-__global__ void k_run_flags(const int32_t* __restrict__ pt_ptr, const int32_t* __restrict__ slot_cam, int32_t n,
-                            int32_t group, int32_t pmax, int32_t* __restrict__ flag) {
-  const int32_t i = blockIdx.x * kT + threadIdx.x;
-  if (i > n) return;
-  int32_t f = 0;
   if (i < n) {
-    if (i == 0 || i % pmax == 0)
-      f = 1;
-    else
-      f = slot_cam[pt_ptr[i]] / group != slot_cam[pt_ptr[i - 1]] / group ? 1 : 0;
+    const int32_t b = pt_ptr[i], e = pt_ptr[i + 1], k = e - b;
+    if (k >= 1 && k <= 8) {
+      atomicAdd(&sh[k], (unsigned long long)k);
+      const int32_t span = slot_cam[e - 1] - slot_cam[b] + 1;
+      if (span <= 8) atomicAdd(&sh[9 + span], (unsigned long long)k);
+    }
   }
-  flag[i] = f;
+  __syncthreads();
+  if (threadIdx.x < 18 && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
 }
 
-__global__ void k_run_fill(const int32_t* __restrict__ flag, const int32_t* __restrict__ rid,
-                           const int32_t* __restrict__ pt_ptr, const int32_t* __restrict__ slot_cam, int32_t n,
-                           int32_t group, int32_t* __restrict__ run_pt0, int32_t* __restrict__ run_base,
-                           uint32_t* __restrict__ run_key, int32_t* __restrict__ run_id, int32_t pmax,
-                           int32_t* __restrict__ rng_run) {
+// window and sort key of every point; a point that fits no window gets the largest key
+__global__ void k_fz_desc(const int32_t* __restrict__ pt_ptr, const int32_t* __restrict__ slot_cam, int32_t n, int slots,
+                          int32_t m, int32_t* __restrict__ desc, uint64_t* __restrict__ key, int32_t* __restrict__ ident,
+                          int32_t* __restrict__ n_cand) {
   const int32_t i = blockIdx.x * kT + threadIdx.x;
-  if (i > n) return;
-  if (i == n) {
-    run_pt0[rid[n]] = n;  // rid[n] = number of runs
-    rng_run[(n + pmax - 1) / pmax] = rid[n];
-  } else if (flag[i]) {
-    if (i % pmax == 0) rng_run[i / pmax] = rid[i];
-    const int32_t r = rid[i], key = slot_cam[pt_ptr[i]] / group;
-    run_pt0[r] = i;
-    run_base[r] = key * group;
-    run_key[r] = (uint32_t)key;
-    run_id[r] = r;
+  bool ok = false;
+  if (i < n) {
+    int32_t d[8];
+    uint64_t k64 = 0;
+    ok = fz_point_window(slot_cam + pt_ptr[i], pt_ptr[i + 1] - pt_ptr[i], slots, m, d, &k64);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) desc[(int64_t)8 * i + s] = ok ? d[s] : -1;
+    key[i] = ok ? k64 : (uint64_t(1) << 33);
+    ident[i] = i;
+  }
+  const unsigned long long any = __ballot(ok);
+  if (any && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(any)) atomicAdd(n_cand, (int32_t)__builtin_popcountll(any));
+}
+
+__device__ inline bool fz_same_window(const int32_t* __restrict__ desc, int32_t a, int32_t b) {
+  bool same = true;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) same = same && desc[(int64_t)8 * a + s] == desc[(int64_t)8 * b + s];
+  return same;
+}
+
+// candidates in sorted order: a window starts where the camera list changes (element n_cand: 0)
+__global__ void k_fz_win_flags(const int32_t* __restrict__ sorted_pt, const int32_t* __restrict__ desc, int32_t n_cand,
+                               int32_t* __restrict__ flag) {
+  const int32_t q = blockIdx.x * kT + threadIdx.x;
+  if (q > n_cand) return;
+  flag[q] = q < n_cand && (q == 0 || !fz_same_window(desc, sorted_pt[q], sorted_pt[q - 1])) ? 1 : 0;
+}
+
+// first candidate of every window (element n_win: n_cand)
+__global__ void k_fz_win_starts(const int32_t* __restrict__ flag, const int32_t* __restrict__ wid_excl, int32_t n_cand,
+                                int32_t* __restrict__ wstart) {
+  const int32_t q = blockIdx.x * kT + threadIdx.x;
+  if (q > n_cand) return;
+  if (q == n_cand)
+    wstart[wid_excl[n_cand]] = n_cand;
+  else if (flag[q])
+    wstart[wid_excl[q]] = q;
+}
+
+// candidates and windows that stay: windows with at least kFzMinWindowPoints points (elements n_cand / n_win: 0)
+__global__ void k_fz_keep(const int32_t* __restrict__ flag, const int32_t* __restrict__ wid_excl,
+                          const int32_t* __restrict__ wstart, int32_t n_cand, int32_t n_win, int32_t* __restrict__ keep,
+                          int32_t* __restrict__ wkeep) {
+  const int32_t q = blockIdx.x * kT + threadIdx.x;
+  if (q <= n_cand) {
+    int32_t kp = 0;
+    if (q < n_cand) {
+      const int32_t w = wid_excl[q] + flag[q] - 1;
+      kp = wstart[w + 1] - wstart[w] >= kFzMinWindowPoints ? 1 : 0;
+    }
+    keep[q] = kp;
+  }
+  if (q <= n_win) wkeep[q] = q < n_win && wstart[q + 1] - wstart[q] >= kFzMinWindowPoints ? 1 : 0;
+}
+
+// near points at their positions: point id, window, whether a window / a run starts there, position of every point
+__global__ void k_fz_place(const int32_t* __restrict__ sorted_pt, const int32_t* __restrict__ flag,
+                           const int32_t* __restrict__ wid_excl, const int32_t* __restrict__ keep,
+                           const int32_t* __restrict__ newpos, const int32_t* __restrict__ newwid,
+                           const int32_t* __restrict__ desc, int32_t n_cand, int32_t n_near, int32_t pmax,
+                           int32_t* __restrict__ fz_pt, int32_t* __restrict__ near_pos, int32_t* __restrict__ pos_key,
+                           int32_t* __restrict__ win_start, int32_t* __restrict__ run_flag, int32_t* __restrict__ key_cam) {
+  const int32_t q = blockIdx.x * kT + threadIdx.x;
+  if (q == n_cand) run_flag[n_near] = 0;
+  if (q >= n_cand || !keep[q]) return;
+  const int32_t pos = newpos[q], i = sorted_pt[q];
+  const int32_t key = newwid[wid_excl[q] + flag[q] - 1];
+  fz_pt[pos] = i;
+  near_pos[i] = pos;
+  pos_key[pos] = key;
+  win_start[pos] = flag[q];
+  run_flag[pos] = (flag[q] || pos % pmax == 0) ? 1 : 0;
+  if (flag[q]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) key_cam[(int64_t)8 * key + s] = desc[(int64_t)8 * i + s];
   }
 }
 
-// steps of 8 points: per run its number of steps (element n_runs: 0, for the prefix sum), then the steps
-__global__ void k_run_step_counts(const int32_t* __restrict__ run_pt0, int32_t n_runs, int32_t* __restrict__ cnt) {
-  const int32_t r = blockIdx.x * kT + threadIdx.x;
-  if (r > n_runs) return;
-  cnt[r] = r < n_runs ? (run_pt0[r + 1] - run_pt0[r] + 7) / 8 : 0;
-}
-
-__global__ void k_step_fill(const int32_t* __restrict__ run_pt0, const int32_t* __restrict__ run_step0, int32_t n_runs,
-                            int32_t* __restrict__ step_pt0, int32_t* __restrict__ step_run) {
-  const int32_t r = blockIdx.x * kT + threadIdx.x;
-  if (r > n_runs) return;
-  if (r == n_runs) {
-    step_run[run_step0[n_runs]] = n_runs;
+__global__ void k_fz_runs(const int32_t* __restrict__ run_flag, const int32_t* __restrict__ rid,
+                          const int32_t* __restrict__ win_start, const int32_t* __restrict__ pos_key,
+                          const int32_t* __restrict__ key_cam, int32_t n_near, int32_t n_keys, int32_t pmax,
+                          int32_t* __restrict__ run_pt0, int32_t* __restrict__ run_key, int32_t* __restrict__ run_cam,
+                          int32_t* __restrict__ key_run, int32_t* __restrict__ rng_run) {
+  const int32_t pos = blockIdx.x * kT + threadIdx.x;
+  if (pos > n_near) return;
+  if (pos == n_near) {
+    const int32_t n_runs = rid[n_near];
+    run_pt0[n_runs] = n_near;
+    key_run[n_keys] = n_runs;
+    rng_run[(n_near + pmax - 1) / pmax] = n_runs;
     return;
   }
-  int32_t k = run_step0[r];
-  for (int32_t f = run_pt0[r]; f < run_pt0[r + 1]; f += 8, ++k) {
-    step_pt0[k] = f;
-    step_run[k] = r;
+  if (!run_flag[pos]) return;
+  const int32_t r = rid[pos], key = pos_key[pos];
+  run_pt0[r] = pos;
+  run_key[r] = key;
+  const int32_t first = key_cam[(int64_t)8 * key];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int32_t c = key_cam[(int64_t)8 * key + s];
+    run_cam[(int64_t)8 * r + s] = c >= 0 ? c : first;
   }
+  if (win_start[pos]) key_run[key] = r;
+  if (pos % pmax == 0) rng_run[pos / pmax] = r;
 }
 
-__global__ void k_range_steps(const int32_t* __restrict__ rng_run, const int32_t* __restrict__ run_step0, int32_t n_ranges,
-                              int32_t* __restrict__ rng_step) {
-  const int32_t g = blockIdx.x * kT + threadIdx.x;
-  if (g <= n_ranges) rng_step[g] = run_step0[rng_run[g]];
-}
-
-// observation of every (point, window slot)
-__global__ void k_slot_obs_fill(const int32_t* __restrict__ pt_ptr, const int32_t* __restrict__ slot_pt,
-                                const int32_t* __restrict__ slot_cam, const int32_t* __restrict__ perm, int64_t N,
-                                int32_t group, int32_t* __restrict__ slot_obs) {
+// observation of every (position, window slot)
+__global__ void k_slot_obs_fill(const int32_t* __restrict__ slot_pt, const int32_t* __restrict__ slot_cam,
+                                const int32_t* __restrict__ perm, const int32_t* __restrict__ near_pos,
+                                const int32_t* __restrict__ desc, int64_t N, int32_t* __restrict__ slot_obs) {
   const int64_t s = (int64_t)blockIdx.x * kT + threadIdx.x;
   if (s >= N) return;
   const int32_t i = slot_pt[s];
-  const int32_t base = slot_cam[pt_ptr[i]] / group * group;
-  slot_obs[(int64_t)i * kFzLanesPerPoint + (slot_cam[s] - base)] = perm[s];
+  const int32_t pos = near_pos[i];
+  if (pos < 0) return;
+  const int32_t c = slot_cam[s];
+  int sl = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    if (desc[(int64_t)8 * i + q] == c) sl = q;
+  slot_obs[(int64_t)pos * kFzLanesPerPoint + sl] = perm[s];
 }
 
-// first position of every key in the sorted key list (lower bound), key_ptr[n_keys] = n_runs
-__global__ void k_key_ptr(const uint32_t* __restrict__ sorted_key, int32_t n_runs, int32_t n_keys,
-                          int32_t* __restrict__ key_ptr) {
+// far points (element n: 0) and far observations (element N: 0), for the prefix sums that number them
+__global__ void k_far_flags(const int32_t* __restrict__ near_pos, const int32_t* __restrict__ pt, int32_t n, int64_t N,
+                            int32_t* __restrict__ pflag, int32_t* __restrict__ oflag) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (i <= n) pflag[i] = i < n && near_pos[i] < 0 ? 1 : 0;
+  if (i <= N) oflag[i] = i < N && near_pos[pt[i]] < 0 ? 1 : 0;
+}
+
+__global__ void k_far_fill(const int32_t* __restrict__ pflag, const int32_t* __restrict__ pnum,
+                           const int32_t* __restrict__ oflag, const int32_t* __restrict__ onum,
+                           const int32_t* __restrict__ cam, const int32_t* __restrict__ pt, int32_t n, int64_t N,
+                           int32_t* __restrict__ far_pt, int32_t* __restrict__ far_obs, int32_t* __restrict__ far_cam,
+                           int32_t* __restrict__ far_lpt, int32_t* __restrict__ far_gpt) {
+  const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (i < n && pflag[i]) far_pt[pnum[i]] = (int32_t)i;
+  if (i < N && oflag[i]) {
+    const int32_t at = onum[i];
+    far_obs[at] = (int32_t)i;
+    far_cam[at] = cam[i];
+    far_lpt[at] = pnum[pt[i]];
+    far_gpt[at] = pt[i];
+  }
+}
+
+// what the finishing kernel adds for every block: one candidate per (window, slot a <= slot b); its sort
+// key is the block of the two cameras (nb: none - a slot without a camera, or a pair without a shared point)
+__global__ void k_fb_candidates(const int32_t* __restrict__ key_cam, int32_t n_keys, const int32_t* __restrict__ seen,
+                                const int32_t* __restrict__ blk_of, int32_t m, int32_t nb, uint32_t* __restrict__ key,
+                                int32_t* __restrict__ val) {
+  const int64_t t = (int64_t)blockIdx.x * kT + threadIdx.x;
+  if (t >= (int64_t)n_keys * 36) return;
+  const int32_t q = (int32_t)(t / 36);
+  int pr = (int)(t - (int64_t)q * 36), a = 0;
+  while (pr >= 8 - a) {  // pairs (a, b >= a) in the order a = 0: 8 of them, a = 1: 7, ...
+    pr -= 8 - a;
+    ++a;
+  }
+  const int b = a + pr;
+  const int32_t ca = key_cam[(int64_t)8 * q + a], cb = key_cam[(int64_t)8 * q + b];
+  int32_t id = nb;
+  if (ca >= 0 && cb >= 0 && seen[(int64_t)ca * m + cb]) id = blk_of[(int64_t)ca * m + cb];
+  key[t] = (uint32_t)id;
+  val[t] = (q << 6) | (a << 3) | b;
+}
+
+// first position of every value 0 .. n_values in a sorted key list (lower bound)
+__global__ void k_lower_bounds(const uint32_t* __restrict__ sorted_key, int64_t count, int32_t n_values,
+                               int32_t* __restrict__ out) {
   const int32_t q = blockIdx.x * kT + threadIdx.x;
-  if (q > n_keys) return;
-  int32_t lo = 0, hi = n_runs;
+  if (q > n_values) return;
+  int64_t lo = 0, hi = count;
   while (lo < hi) {
-    const int32_t mid = (lo + hi) >> 1;
+    const int64_t mid = (lo + hi) >> 1;
     if (sorted_key[mid] < (uint32_t)q)
       lo = mid + 1;
     else
       hi = mid;
   }
-  key_ptr[q] = lo;
+  out[q] = (int32_t)lo;
+}
+
+// partial results the far plan keeps for every block of this plan (the far plan's blocks are sorted by (j, k))
+__global__ void k_fb_far(const int32_t* __restrict__ blk_j, const int32_t* __restrict__ blk_k, int32_t nb,
+                         const int32_t* __restrict__ far_j, const int32_t* __restrict__ far_k,
+                         const int32_t* __restrict__ far_part, const int32_t* __restrict__ far_cnt, int32_t nfb, int32_t m,
+                         int32_t* __restrict__ out_part, int32_t* __restrict__ out_cnt) {
+  const int32_t b = blockIdx.x * kT + threadIdx.x;
+  if (b >= nb) return;
+  const int64_t want = (int64_t)blk_j[b] * m + blk_k[b];
+  int32_t lo = 0, hi = nfb;
+  while (lo < hi) {
+    const int32_t mid = (lo + hi) >> 1;
+    if ((int64_t)far_j[mid] * m + far_k[mid] < want)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  const bool found = lo < nfb && (int64_t)far_j[lo] * m + far_k[lo] == want;
+  out_part[b] = found ? far_part[lo] : -1;
+  out_cnt[b] = found ? far_cnt[lo] : 0;
 }
 
 template <typename T>
@@ -417,8 +550,12 @@ int keep(T** field, int64_t count, int64_t* bytes) {
     if (rc__ != SFM_BA_OK) return rc__; \
   } while (0)
 
-int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int32_t n_hint, int check, hipStream_t st,
-          sfm_ba_plan* p) {
+enum PlanFlags { kPlanNoFused = 1, kPlanForceParts = 2 };
+
+int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int32_t n_hint, int check, int flags,
+          hipStream_t st, sfm_ba_plan* p) {
+  const int force = (flags & kPlanForceParts) ? 1 : 0;
+  p->force_parts = force;
   Scratch scratch;
   int64_t bytes = 0;
   int32_t* d_stats = nullptr;
@@ -431,6 +568,7 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
   };
   {
     int32_t init[ST_COUNT] = {-1, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static_assert(ST_COUNT == 11, "one initial value per statistic");
     SFMBA_HIP(hipMemcpyAsync(d_stats, init, sizeof(init), hipMemcpyHostToDevice, st));
     SFMBA_HIP(hipStreamSynchronize(st));  // `init` leaves scope
   }
@@ -496,15 +634,12 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
   k_idx_keys<<<blocks_for(N), kT, 0, st>>>(cam, pt, N, cam_bits, key64, ident, cam_key);
   SFMBA_TRY(sort_pairs(key64, key64_sorted, ident, p->d_perm, N, cam_bits + pt_bits, scratch, st));
   k_idx_unpack<<<blocks_for(N), kT, 0, st>>>(key64_sorted, N, cam_bits, p->d_slot_cam, slot_pt, d_stats);
-  k_point_span<<<blocks_for(n), kT, 0, st>>>(p->d_pt_ptr, p->d_slot_cam, n, d_stats);
   if (!cam_sorted) {
     SFMBA_TRY(keep(&p->d_cam_obs, N, &bytes));
     SFMBA_TRY(sort_pairs(cam_key, cam_key + N, ident, p->d_cam_obs, N, cam_bits, scratch, st));
   }
   SFMBA_TRY(read_stats());
   if (check && h[ST_NONUNIQUE]) return SFM_BA_ENONUNIQUE;
-  const int32_t span_max = h[ST_SPAN_MAX];
-  const bool empty_point = h[ST_EMPTY_PT] != 0;
   if (N * 112 >= (int64_t(1) << 32)) return SFM_BA_ETOOBIG;  // 32-bit byte offsets into A
   // 32-bit byte offsets into T, counted from the start of g that precedes it in the workspace
   if (N * 16 + 256 + (pairs + kPairPad) * 32 >= (int64_t(1) << 32)) return SFM_BA_ETOOBIG;
@@ -582,7 +717,7 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
   parts = multi + (nb + 1);
   multi_off = item_off + (nb + 1);
   part_off = multi_off + (nb + 1);
-  k_block_chunks<<<blocks_for(nb + 1), kT, 0, st>>>(blk_ptr, nb, chunks, multi, parts);
+  k_block_chunks<<<blocks_for(nb + 1), kT, 0, st>>>(blk_ptr, nb, force, chunks, multi, parts);
   SFMBA_TRY(scan_exclusive(chunks, item_off, nb + 1, scratch, st));
   SFMBA_TRY(scan_exclusive(multi, multi_off, nb + 1, scratch, st));
   SFMBA_TRY(scan_exclusive(parts, part_off, nb + 1, scratch, st));
@@ -602,67 +737,165 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
   SFMBA_TRY(keep(&p->d_mb_blk, totals[1], &bytes));
   SFMBA_TRY(keep(&p->d_mb_part, totals[1], &bytes));
   SFMBA_TRY(keep(&p->d_mb_cnt, totals[1], &bytes));
-  k_pair_items_fill<<<blocks_for(nb), kT, 0, st>>>(blk_ptr, item_off, multi_off, part_off, nb, p->d_pit_blk, p->d_pit_beg,
+  k_pair_items_fill<<<blocks_for(nb), kT, 0, st>>>(blk_ptr, item_off, multi_off, part_off, nb, force, p->d_pit_blk, p->d_pit_beg,
                                                    p->d_pit_end, p->d_pit_part, p->d_mb_blk, p->d_mb_part, p->d_mb_cnt);
 
-  // ---- runs of the fused point-major assembly (same rule as the host builder) ----
-  FzShape sh;
-  if (fz_shape(n, span_max, empty_point, &sh)) {
-    int32_t *flag, *rid;
-    SFMBA_HIP(scratch.get(&flag, n + 1));
-    SFMBA_HIP(scratch.get(&rid, n + 1));
-    k_run_flags<<<blocks_for(n + 1), kT, 0, st>>>(p->d_pt_ptr, p->d_slot_cam, n, sh.group, sh.pmax, flag);
-    SFMBA_TRY(scan_exclusive(flag, rid, n + 1, scratch, st));
-    int32_t n_runs = 0;
-    SFMBA_HIP(hipMemcpyAsync(&n_runs, rid + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  // ---- near points of the fused point-major assembly, far points (same rules as the host builder) ----
+  // (a list that names a (camera, point) pair twice - accepted only without checks - stays on the
+  // camera-pair path, which adds both; the slot table of the fused path has room for one)
+  int slots = 0;
+  if (!(flags & kPlanNoFused) && !h[ST_NONUNIQUE]) {
+    unsigned long long* hist;
+    SFMBA_HIP(scratch.get(&hist, 18));
+    SFMBA_HIP(hipMemsetAsync(hist, 0, 18 * sizeof(unsigned long long), st));
+    k_fz_hist<<<blocks_for(n), kT, 0, st>>>(p->d_pt_ptr, p->d_slot_cam, n, hist);
+    unsigned long long hh[18];
+    SFMBA_HIP(hipMemcpyAsync(hh, hist, sizeof(hh), hipMemcpyDeviceToHost, st));
     SFMBA_HIP(hipStreamSynchronize(st));
-    if (fz_worthwhile(n, n_runs)) {
-      p->fz_slots = sh.slots;
-      p->fz_group = sh.group;
-      p->fz_pmax = sh.pmax;
+    int64_t obs_by_k[9], obs_by_span[9];
+    for (int v = 0; v < 9; ++v) {
+      obs_by_k[v] = (int64_t)hh[v];
+      obs_by_span[v] = (int64_t)hh[9 + v];
+    }
+    slots = fz_choose_slots(obs_by_k, obs_by_span);
+  }
+  if (slots > 0) {
+    // windows and sort keys; candidates sorted by key (stable: ascending point id inside a key)
+    int32_t *desc, *ident, *sorted_pt;
+    uint64_t *wkey, *wkey_sorted;
+    SFMBA_HIP(scratch.get(&desc, (int64_t)8 * n));
+    SFMBA_HIP(scratch.get(&ident, n));
+    SFMBA_HIP(scratch.get(&sorted_pt, n));
+    SFMBA_HIP(scratch.get(&wkey, n));
+    SFMBA_HIP(scratch.get(&wkey_sorted, n));
+    k_fz_desc<<<blocks_for(n), kT, 0, st>>>(p->d_pt_ptr, p->d_slot_cam, n, slots, m, desc, wkey, ident, d_stats + ST_N_CAND);
+    SFMBA_TRY(sort_pairs(wkey, wkey_sorted, ident, sorted_pt, n, 34, scratch, st));
+    SFMBA_TRY(read_stats());
+    const int32_t n_cand = h[ST_N_CAND];
+    // windows of the sorted candidates, the ones long enough to keep, positions of the near points
+    int32_t *flag, *wid_excl, *wstart, *keepf, *wkeep, *newpos, *newwid;
+    SFMBA_HIP(scratch.get(&flag, n_cand + 1));
+    SFMBA_HIP(scratch.get(&wid_excl, n_cand + 1));
+    k_fz_win_flags<<<blocks_for(n_cand + 1), kT, 0, st>>>(sorted_pt, desc, n_cand, flag);
+    SFMBA_TRY(scan_exclusive(flag, wid_excl, n_cand + 1, scratch, st));
+    int32_t n_win = 0;
+    SFMBA_HIP(hipMemcpyAsync(&n_win, wid_excl + n_cand, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SFMBA_HIP(hipStreamSynchronize(st));
+    SFMBA_HIP(scratch.get(&wstart, n_win + 1));
+    SFMBA_HIP(scratch.get(&keepf, n_cand + 1));
+    SFMBA_HIP(scratch.get(&newpos, n_cand + 1));
+    SFMBA_HIP(scratch.get(&wkeep, n_win + 1));
+    SFMBA_HIP(scratch.get(&newwid, n_win + 1));
+    k_fz_win_starts<<<blocks_for(n_cand + 1), kT, 0, st>>>(flag, wid_excl, n_cand, wstart);
+    k_fz_keep<<<blocks_for(std::max(n_cand, n_win) + 1), kT, 0, st>>>(flag, wid_excl, wstart, n_cand, n_win, keepf, wkeep);
+    SFMBA_TRY(scan_exclusive(keepf, newpos, n_cand + 1, scratch, st));
+    SFMBA_TRY(scan_exclusive(wkeep, newwid, n_win + 1, scratch, st));
+    int32_t n_near = 0, n_keys = 0;
+    SFMBA_HIP(hipMemcpyAsync(&n_near, newpos + n_cand, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SFMBA_HIP(hipMemcpyAsync(&n_keys, newwid + n_win, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SFMBA_HIP(hipStreamSynchronize(st));
+    const int32_t pmax = fz_pmax_for(n_near);
+    int32_t n_runs = 0;
+    int32_t *near_pos, *fz_pt = nullptr, *pos_key = nullptr, *win_start = nullptr, *run_flag = nullptr, *rid = nullptr,
+            *key_cam = nullptr;
+    SFMBA_HIP(scratch.get(&near_pos, n));
+    SFMBA_HIP(hipMemsetAsync(near_pos, 0xFF, sizeof(int32_t) * (size_t)std::max(n, 1), st));
+    if (n_near > 0) {
+      SFMBA_HIP(scratch.get(&fz_pt, n_near));
+      SFMBA_HIP(scratch.get(&pos_key, n_near));
+      SFMBA_HIP(scratch.get(&win_start, n_near));
+      SFMBA_HIP(scratch.get(&run_flag, n_near + 1));
+      SFMBA_HIP(scratch.get(&rid, n_near + 1));
+      SFMBA_HIP(scratch.get(&key_cam, (int64_t)8 * n_keys));
+      k_fz_place<<<blocks_for(n_cand + 1), kT, 0, st>>>(sorted_pt, flag, wid_excl, keepf, newpos, newwid, desc, n_cand, n_near,
+                                                       pmax, fz_pt, near_pos, pos_key, win_start, run_flag, key_cam);
+      SFMBA_TRY(scan_exclusive(run_flag, rid, n_near + 1, scratch, st));
+      SFMBA_HIP(hipMemcpyAsync(&n_runs, rid + n_near, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      SFMBA_HIP(hipStreamSynchronize(st));
+    }
+    // far points and their observations (before the decision: it needs their number)
+    int32_t *pflag, *pnum, *oflag, *onum;
+    SFMBA_HIP(scratch.get(&pflag, n + 1));
+    SFMBA_HIP(scratch.get(&pnum, n + 1));
+    SFMBA_HIP(scratch.get(&oflag, N + 1));
+    SFMBA_HIP(scratch.get(&onum, N + 1));
+    k_far_flags<<<blocks_for(std::max<int64_t>(n, N) + 1), kT, 0, st>>>(near_pos, pt, n, N, pflag, oflag);
+    SFMBA_TRY(scan_exclusive(pflag, pnum, n + 1, scratch, st));
+    SFMBA_TRY(scan_exclusive(oflag, onum, N + 1, scratch, st));
+    int32_t n_far = 0, n_far_obs = 0;
+    SFMBA_HIP(hipMemcpyAsync(&n_far, pnum + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SFMBA_HIP(hipMemcpyAsync(&n_far_obs, onum + N, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SFMBA_HIP(hipStreamSynchronize(st));
+    // (points without observations - allowed on plans built with size hints - go with the far points)
+    if (fz_worthwhile(n, n_near, n_runs)) {
+      p->fz_slots = slots;
+      p->fz_pmax = pmax;
+      p->n_near = n_near;
       p->n_runs = n_runs;
-      p->n_keys = (m - 1) / sh.group + 1;
-      uint32_t *run_key, *run_key_sorted;
-      int32_t* run_id;
-      SFMBA_HIP(scratch.get(&run_key, n_runs));
-      SFMBA_HIP(scratch.get(&run_key_sorted, n_runs));
-      SFMBA_HIP(scratch.get(&run_id, n_runs));
+      p->n_keys = n_keys;
+      p->n_ranges = (n_near + pmax - 1) / pmax;
+      p->n_far = n_far;
+      p->n_far_obs = n_far_obs;
+      SFMBA_TRY(keep(&p->d_fz_pt, n_near, &bytes));
+      SFMBA_HIP(hipMemcpyAsync(p->d_fz_pt, fz_pt, sizeof(int32_t) * (size_t)n_near, hipMemcpyDeviceToDevice, st));
+      SFMBA_TRY(keep(&p->d_key_cam, (int64_t)8 * n_keys, &bytes));
+      SFMBA_HIP(hipMemcpyAsync(p->d_key_cam, key_cam, sizeof(int32_t) * 8 * (size_t)n_keys, hipMemcpyDeviceToDevice, st));
       SFMBA_TRY(keep(&p->d_run_pt0, n_runs + 1, &bytes));
-      SFMBA_TRY(keep(&p->d_run_base, n_runs, &bytes));
-      SFMBA_TRY(keep(&p->d_slot_obs, (int64_t)n * kFzLanesPerPoint, &bytes));
-      SFMBA_TRY(keep(&p->d_key_ptr, p->n_keys + 1, &bytes));
-      SFMBA_TRY(keep(&p->d_key_run, n_runs, &bytes));
-      p->n_ranges = (n + sh.pmax - 1) / sh.pmax;
+      SFMBA_TRY(keep(&p->d_run_key, n_runs, &bytes));
+      SFMBA_TRY(keep(&p->d_run_cam, (int64_t)8 * n_runs, &bytes));
+      SFMBA_TRY(keep(&p->d_key_run, n_keys + 1, &bytes));
       SFMBA_TRY(keep(&p->d_rng_run, p->n_ranges + 1, &bytes));
-      k_run_fill<<<blocks_for(n + 1), kT, 0, st>>>(flag, rid, p->d_pt_ptr, p->d_slot_cam, n, sh.group, p->d_run_pt0,
-                                                  p->d_run_base, run_key, run_id, sh.pmax, p->d_rng_run);
-      SFMBA_HIP(hipMemsetAsync(p->d_slot_obs, 0xFF, sizeof(int32_t) * (size_t)n * kFzLanesPerPoint, st));
-      k_slot_obs_fill<<<blocks_for(N), kT, 0, st>>>(p->d_pt_ptr, slot_pt, p->d_slot_cam, p->d_perm, N, sh.group,
-                                                   p->d_slot_obs);
+      k_fz_runs<<<blocks_for(n_near + 1), kT, 0, st>>>(run_flag, rid, win_start, pos_key, p->d_key_cam, n_near, n_keys, pmax,
+                                                      p->d_run_pt0, p->d_run_key, p->d_run_cam, p->d_key_run, p->d_rng_run);
+      SFMBA_TRY(keep(&p->d_slot_obs, (int64_t)n_near * kFzLanesPerPoint, &bytes));
+      SFMBA_HIP(hipMemsetAsync(p->d_slot_obs, 0xFF, sizeof(int32_t) * (size_t)n_near * kFzLanesPerPoint, st));
+      k_slot_obs_fill<<<blocks_for(N), kT, 0, st>>>(slot_pt, p->d_slot_cam, p->d_perm, near_pos, desc, N, p->d_slot_obs);
       {
-        int32_t *step_cnt, *run_step0;
-        SFMBA_HIP(scratch.get(&step_cnt, n_runs + 1));
-        SFMBA_HIP(scratch.get(&run_step0, n_runs + 1));
-        k_run_step_counts<<<blocks_for(n_runs + 1), kT, 0, st>>>(p->d_run_pt0, n_runs, step_cnt);
-        SFMBA_TRY(scan_exclusive(step_cnt, run_step0, n_runs + 1, scratch, st));
-        int32_t n_steps = 0;
-        SFMBA_HIP(hipMemcpyAsync(&n_steps, run_step0 + n_runs, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        // steps of 8 points, most runs of a range: from the run boundaries, on the host
+        std::vector<int32_t> rp((size_t)n_runs + 1), rr((size_t)p->n_ranges + 1);
+        SFMBA_HIP(hipMemcpyAsync(rp.data(), p->d_run_pt0, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, st));
+        SFMBA_HIP(hipMemcpyAsync(rr.data(), p->d_rng_run, sizeof(int32_t) * rr.size(), hipMemcpyDeviceToHost, st));
         SFMBA_HIP(hipStreamSynchronize(st));
-        p->n_steps = n_steps;
-        {
-          std::vector<int32_t> rr((size_t)p->n_ranges + 1);
-          SFMBA_HIP(hipMemcpy(rr.data(), p->d_rng_run, sizeof(int32_t) * rr.size(), hipMemcpyDeviceToHost));
-          for (int32_t g = 0; g < p->n_ranges; ++g)
-            p->fz_max_range_runs = std::max(p->fz_max_range_runs, rr[(size_t)g + 1] - rr[(size_t)g]);
-        }
-        SFMBA_TRY(keep(&p->d_step_pt0, n_steps, &bytes));
-        SFMBA_TRY(keep(&p->d_step_run, n_steps + 1, &bytes));
-        SFMBA_TRY(keep(&p->d_rng_step, p->n_ranges + 1, &bytes));
-        k_step_fill<<<blocks_for(n_runs + 1), kT, 0, st>>>(p->d_run_pt0, run_step0, n_runs, p->d_step_pt0, p->d_step_run);
-        k_range_steps<<<blocks_for(p->n_ranges + 1), kT, 0, st>>>(p->d_rng_run, run_step0, p->n_ranges, p->d_rng_step);
+        for (int32_t r = 0; r < n_runs; ++r) p->n_steps += (rp[(size_t)r + 1] - rp[(size_t)r] + 7) / 8;
+        for (int32_t g = 0; g < p->n_ranges; ++g)
+          p->fz_max_range_runs = std::max(p->fz_max_range_runs, rr[(size_t)g + 1] - rr[(size_t)g]);
       }
-      SFMBA_TRY(sort_pairs(run_key, run_key_sorted, run_id, p->d_key_run, n_runs, bits_for(p->n_keys), scratch, st));
-      k_key_ptr<<<blocks_for(p->n_keys + 1), kT, 0, st>>>(run_key_sorted, n_runs, p->n_keys, p->d_key_ptr);
+      SFMBA_TRY(keep(&p->d_far_pt, n_far, &bytes));
+      SFMBA_TRY(keep(&p->d_far_obs, n_far_obs, &bytes));
+      SFMBA_TRY(keep(&p->d_far_cam, n_far_obs, &bytes));
+      SFMBA_TRY(keep(&p->d_far_lpt, n_far_obs, &bytes));
+      SFMBA_TRY(keep(&p->d_far_gpt, n_far_obs, &bytes));
+      k_far_fill<<<blocks_for(std::max<int64_t>(n, N)), kT, 0, st>>>(pflag, pnum, oflag, onum, cam, pt, n, N, p->d_far_pt,
+                                                                  p->d_far_obs, p->d_far_cam, p->d_far_lpt, p->d_far_gpt);
+      if (n_far_obs > 0) {
+        p->far = new (std::nothrow) sfm_ba_plan();
+        if (!p->far) return SFM_BA_EINVAL;
+        SFMBA_TRY(build(p->d_far_cam, p->d_far_lpt, n_far_obs, m, n_far, 0, kPlanNoFused | kPlanForceParts, st, p->far));
+      }
+      // entries of the finishing kernel: candidates sorted by block (stable: ascending window inside a block)
+      const int64_t n_fc = (int64_t)n_keys * 36;
+      uint32_t *fkey, *fkey_sorted;
+      int32_t *fval, *fval_sorted;
+      SFMBA_HIP(scratch.get(&fkey, n_fc));
+      SFMBA_HIP(scratch.get(&fkey_sorted, n_fc));
+      SFMBA_HIP(scratch.get(&fval, n_fc));
+      SFMBA_HIP(scratch.get(&fval_sorted, n_fc));
+      k_fb_candidates<<<blocks_for(n_fc), kT, 0, st>>>(p->d_key_cam, n_keys, seen, blk_of, m, nb, fkey, fval);
+      SFMBA_TRY(sort_pairs(fkey, fkey_sorted, fval, fval_sorted, n_fc, bits_for((int64_t)nb + 1), scratch, st));
+      SFMBA_TRY(keep(&p->d_fb_ptr, nb + 1, &bytes));
+      k_lower_bounds<<<blocks_for(nb + 1), kT, 0, st>>>(fkey_sorted, n_fc, nb, p->d_fb_ptr);
+      int32_t n_fb = 0;
+      SFMBA_HIP(hipMemcpyAsync(&n_fb, p->d_fb_ptr + nb, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      SFMBA_HIP(hipStreamSynchronize(st));
+      p->n_fb = n_fb;
+      SFMBA_TRY(keep(&p->d_fb_ent, n_fb, &bytes));
+      SFMBA_HIP(hipMemcpyAsync(p->d_fb_ent, fval_sorted, sizeof(int32_t) * (size_t)n_fb, hipMemcpyDeviceToDevice, st));
+      SFMBA_TRY(keep(&p->d_fb_far_part, nb, &bytes));
+      SFMBA_TRY(keep(&p->d_fb_far_cnt, nb, &bytes));
+      const sfm_ba_plan* f = p->far;
+      k_fb_far<<<blocks_for(nb), kT, 0, st>>>(p->d_blk_j, p->d_blk_k, nb, f ? f->d_blk_j : nullptr, f ? f->d_blk_k : nullptr,
+                                             f ? f->d_mb_part : nullptr, f ? f->d_mb_cnt : nullptr, f ? f->n_blocks : 0, m,
+                                             p->d_fb_far_part, p->d_fb_far_cnt);
     }
   }
   SFMBA_HIP(hipGetLastError());
@@ -683,7 +916,7 @@ extern "C" int sfm_ba_plan_create_device(const int32_t* d_cam_idx, const int32_t
   if (!d_cam_idx || !d_pt_idx || n_obs <= 0 || n_obs >= (int64_t(1) << 31)) return SFM_BA_EINVAL;
   sfm_ba_plan* p = new (std::nothrow) sfm_ba_plan();
   if (!p) return SFM_BA_EINVAL;
-  const int rc = sfmba::build(d_cam_idx, d_pt_idx, n_obs, n_cams_hint, n_pts_hint, check, static_cast<hipStream_t>(stream), p);
+  const int rc = sfmba::build(d_cam_idx, d_pt_idx, n_obs, n_cams_hint, n_pts_hint, check, 0, static_cast<hipStream_t>(stream), p);
   if (rc != SFM_BA_OK) {
     sfm_ba_plan_destroy(p);
     return rc;

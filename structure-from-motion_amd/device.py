@@ -45,10 +45,21 @@ class Plan:
 
     FIELDS = ("pt_ptr", "perm", "slot_cam", "tp_ptr", "pair_entry", "grp_pt", "cam_obs", "item_cam", "item_beg",
               "item_end", "cam_item_ptr", "blk_j", "blk_k", "entries", "pit_blk", "pit_beg", "pit_end", "pit_part",
-              "mb_blk", "mb_part", "mb_cnt", "run_pt0", "run_base", "slot_obs", "key_ptr", "key_run", "rng_run", "step_pt0", "step_run", "rng_step")
+              "mb_blk", "mb_part", "mb_cnt", "run_pt0", "run_key", "slot_obs", "key_cam", "key_run", "rng_run", "fz_pt",
+              "run_cam", "fb_ptr", "fb_ent", "fb_far_part", "fb_far_cnt", "far_pt", "far_obs", "far_cam", "far_lpt",
+              "far_gpt")
+    # the arrays of the fused assembly and of the near / far split
+    FUSED_FIELDS = FIELDS[21:]
 
-    def __init__(self, cam_idx, pt_idx, n_cams_hint=0, n_pts_hint=0, check=True, where="device"):
+    def __init__(self, cam_idx, pt_idx, n_cams_hint=0, n_pts_hint=0, check=True, where="device", _borrowed=None):
         lib = _lib.load()
+        if _borrowed is not None:
+            # the far plan of another plan: owned by that plan, which this object keeps alive
+            self._lib = lib
+            self._owner, self.handle = _borrowed
+            self._read_sizes()
+            return
+        self._owner = None
         dev = _dev()
         handle = C.c_void_p()
         if where == "host":
@@ -75,6 +86,10 @@ class Plan:
         _lib.check(rc)
         self._lib = lib
         self.handle = handle
+        self._read_sizes()
+
+    def _read_sizes(self):
+        lib, handle = self._lib, self.handle
         sizes = (C.c_int64 * 8)()
         _lib.check(lib.sfm_ba_plan_sizes(handle, sizes))
         (self.m, self.n, self.n_obs, self.n_blocks, self.n_entries, self.n_pair_slots,
@@ -83,9 +98,14 @@ class Plan:
         self.half_bandwidth = int(lib.sfm_ba_plan_half_bandwidth(handle))
         info = (C.c_int32 * 8)()
         _lib.check(lib.sfm_ba_plan_fused_info(handle, info))
-        # runs of the fused point-major assembly (0 runs: the visibility pattern does not allow it)
-        (self.fused, self.fused_slots, self.fused_group, self.fused_pmax, self.n_runs, self.n_keys, self.n_steps,
+        # fused point-major assembly over the near points (0 runs: the plan has no such path)
+        (self.fused, self.fused_slots, self.n_near, self.fused_pmax, self.n_runs, self.n_keys, self.n_steps,
          self.n_ranges) = [int(v) for v in info]
+        far = lib.sfm_ba_plan_far(handle)
+        # far points: a plan of their own (camera-pair kernels), None when every point is near
+        self.far = Plan(None, None, _borrowed=(self, C.c_void_p(far))) if far else None
+        self.n_far = self.far.n if self.far is not None else (self.n - self.n_near if self.n_runs > 0 else 0)
+        self.n_far_obs = self.far.n_obs if self.far is not None else 0
 
     def set_fused(self, enable):
         """Turn the fused point-major assembly of this plan on or off (on by default where runs exist)."""
@@ -104,6 +124,8 @@ class Plan:
 
     def __del__(self):
         h = getattr(self, "handle", None)
+        if getattr(self, "_owner", None) is not None:
+            return
         if h is not None and h.value:
             self._lib.sfm_ba_plan_destroy(h)
             self.handle = None
@@ -125,21 +147,18 @@ class DeviceProblem:
     X_STEP = 0.5   # :100
 
     def __init__(self, K, R, T, X, cam_idx, pt_idx, x_true, n_cams=None, group=None, check=True, device=None,
-                 sharded=None, plan_where="device", steps=False, state=None, reorder=False):
+                 sharded=None, plan_where="device", state=None, reorder=False, cam_order=None):
         self.lib = _lib.load()
         # reorder: when S is not a narrow band in the order given, look for a camera order in which
         # it is narrower (ordering.narrowest_order: a sequence that closes a loop) and keep the cameras
         # in that order on the device.  cameras() / set_state() translate; S, delta_a and everything
         # per observation are then in the device's order (cam_order[i] = caller's index of camera i).
+        # cam_order: that order, given by the caller (the ranks of a sharded run must agree on it:
+        # ordering.narrowest_order on the unsharded lists, before the points are dealt out).
         self.cam_order = None
         self.cam_pos = None
         self.natural_half_bandwidth = None
         self.device = _dev(device)
-        # steps: keep the rows of A as step blocks (plans with runs only).  The assembly kernel then
-        # reads whole contiguous KiB, but the blocks carry the empty (point, camera slot) lanes along,
-        # and the Jacobian and back-substitution kernels lose more than the assembly gains (measured
-        # on 500 cameras x 300 000 points: 0.495 ms per iteration against 0.476 ms): off by default.
-        self.use_steps = bool(steps)
         # state: form the rows of A inside the assembly and back-substitution kernels instead of
         # writing A once and reading it twice (plans with runs; default on, SFM_BA_STATE=0 turns it off)
         self._want_state = (os.environ.get("SFM_BA_STATE", "1") != "0") if state is None else bool(state)
@@ -163,21 +182,31 @@ class DeviceProblem:
         K = np.asarray(K, dtype=np.float64)
         T = np.asarray(T, dtype=np.float64).reshape(-1, 3)
         x_true = np.ascontiguousarray(x_true, dtype=np.float64).reshape(-1, 2)
-        if reorder and group is None and self.N > 0:
+        order = pos = None
+        if cam_order is not None:
+            order = np.asarray(cam_order, dtype=np.int64)
+            assert order.shape == (self.m,) and np.array_equal(np.sort(order), np.arange(self.m))
+            pos = np.empty(self.m, dtype=np.int64)
+            pos[order] = np.arange(self.m)
+        elif reorder and group is None and self.N > 0:
             from . import ordering
 
             hb_nat = ordering.half_bandwidth(np.arange(self.m), cam_idx, pt_idx, self.n)
             self.natural_half_bandwidth = hb_nat
             if hb_nat > 64:
-                hb_new, pos, order = ordering.narrowest_order(cam_idx, pt_idx, self.m, self.n, hb_nat)
+                hb_new, pos_new, order_new = ordering.narrowest_order(cam_idx, pt_idx, self.m, self.n, hb_nat)
                 # worth it when the band halves: up to 256 it reaches a band solver, above that the
                 # general factorisation still skips the zero tiles outside it
-                if pos is not None and 2 * hb_new <= hb_nat:
-                    cam_idx, pt_idx, x_true, _ = ordering.reorder_observations(pos, cam_idx, pt_idx, x_true)
-                    R, T = R[order], T[order]
-                    if K.ndim == 3:
-                        K = K[order]
-                    self.cam_order, self.cam_pos = order, pos
+                if pos_new is not None and 2 * hb_new <= hb_nat:
+                    order, pos = order_new, pos_new
+        if order is not None:
+            from . import ordering
+
+            cam_idx, pt_idx, x_true, _ = ordering.reorder_observations(pos, cam_idx, pt_idx, x_true)
+            R, T = R[order], T[order]
+            if K.ndim == 3:
+                K = K[order]
+            self.cam_order, self.cam_pos = order, pos
         sharded = self.sharded
         hinted = sharded or not check
         with torch.cuda.device(self.device):
@@ -192,8 +221,7 @@ class DeviceProblem:
         # band of the reduced camera matrix: the widest over all shards
         self.half_bandwidth = self.plan.half_bandwidth
         # rows of A formed inside the kernels that use them (plans with runs)
-        self.from_state = (self._want_state and not self.use_steps
-                           and bool(self.lib.sfm_ba_plan_state_path(self.plan.handle)))
+        self.from_state = self._want_state and bool(self.lib.sfm_ba_plan_state_path(self.plan.handle))
         if self.sharded and self.world > 1:
             import torch.distributed as dist
 
@@ -279,9 +307,6 @@ class DeviceProblem:
         self.tri = None  # dense sharded exchange buffer, allocated by the first such exchange
         self.cost_buf = torch.zeros((1,), dtype=F64, device=d)
         self.status_buf = torch.zeros((3,), dtype=F64, device=d)
-        # step blocks: rows of A and residuals in the order the fused assembly walks them (plans with runs)
-        n_el = int(self.lib.sfm_ba_plan_steps_elements(self.plan.handle)) if self.use_steps else 0
-        self.steps = torch.empty((n_el,), dtype=F64, device=d) if n_el > 0 else None
 
     # -- single stages ---------------------------------------------------------------------
     def camera_prepare(self):
@@ -298,51 +323,18 @@ class DeviceProblem:
                                             self.N, p(self.A), p(self.B) if want_B else None,
                                             p(self.x_pred) if want_pred else None, _stream()))
 
-    def jacobian_steps(self):
-        """Rows of A and residuals as step blocks (plans with runs): what ``assemble(steps=True)`` and
-        ``back_substitute(steps=True)`` read instead of A, x_true and x_pred."""
-        p = _lib.ptr
-        _lib.check(self.lib.sfm_ba_jacobian_steps(self.plan.handle, p(self.cam_blk), p(self.P), p(self.X),
-                                                  p(self.x_true), p(self.steps), _stream()))
-
     def predict(self):
         p = _lib.ptr
         _lib.check(self.lib.sfm_ba_jacobian(p(self.cam_blk), p(self.P), p(self.X), p(self.cam_idx), p(self.pt_idx),
                                             self.N, None, None, p(self.x_pred), _stream()))
 
-    def assemble_state(self, mu):
-        """Jacobian blocks and Schur assembly in one pass (plans with runs): the rows of A are formed
-        inside the assembly kernel from the camera records and the points and never written."""
-        p = _lib.ptr
-        mu_u = 0.0 if self.sharded else mu
-        n7 = self.n7
-        self._packed_mu = float(mu) if self.band_sharded else None
-        _lib.check(self.lib.sfm_ba_schur_assemble_state(
-            self.plan.handle, p(self.cam_blk), p(self.P), p(self.X), p(self.x_true), float(mu), float(mu_u),
-            p(self.S), p(self.e), p(self.V_inv), p(self.eps_b), p(self.workspace), _stream()))
-        if self.band_sharded:
-            _lib.check(self.lib.sfm_ba_band_compact(p(self.S), n7, self.half_bandwidth, p(self.compact), _stream()))
-            self._all_reduce(self.compact)
-            _lib.check(self.lib.sfm_ba_band_expand(p(self.compact), n7, self.half_bandwidth, p(self.packed), _stream()))
-
-    def back_substitute_state(self, update_points=False):
-        """delta_b (and the point update) with the rows of A formed again from the state."""
-        p = _lib.ptr
-        _lib.check(self.lib.sfm_ba_back_substitute_state(
-            self.plan.handle, p(self.cam_blk), p(self.V_inv), p(self.eps_b), p(self.delta_a), p(self.delta_b),
-            p(self.X), 1 if update_points else 0, float(self.X_STEP), _stream()))
-
-    def assemble(self, mu, weights=None, x_true=None, x_pred=None, A=None, B=None, by_products=True,
-                 reduce_packed=False, steps=False):
-        """``by_products=False`` skips U and eps_a (the solve needs only S and e): the library then
-        folds the per-camera sums into the camera-pair kernel and makes one pass less over A."""
-        p = _lib.ptr
-        mu_u = 0.0 if self.sharded else mu
+    def _prepare_system(self, mu, reduce_packed):
+        """Before an assembly: the damping that goes into U, and S cleared where the kernels will not
+        write while a solver or an earlier exchange may have left something."""
         n7 = self.n7
         # ``reduce_packed`` (sharded run, narrow band): the ranks exchange the packed block-tridiagonal
         # form instead of the dense buffer; S then keeps this rank's sums only and solve() works
         # from ``self.packed``.
-        reduce_packed = bool(reduce_packed) and self.band_sharded
         self._packed_mu = float(mu) if reduce_packed else None
         if reduce_packed and self._s_holds_foreign:
             # an earlier dense exchange left other ranks' sums in blocks this rank never writes
@@ -355,18 +347,13 @@ class DeviceProblem:
             # all-reduce of a sharded run left the other ranks' blocks there
             # (row n7, the right-hand side, included: a shard need not observe every camera)
             self.sys[: (n7 + 1) * n7].zero_()
-        if steps:
-            _lib.check(self.lib.sfm_ba_schur_assemble_steps(
-                self.plan.handle, p(self.steps), float(mu), float(mu_u), p(self.S), p(self.e), p(self.V_inv),
-                p(self.eps_b), p(self.workspace), _stream()))
-        else:
-            _lib.check(self.lib.sfm_ba_schur_assemble(
-                self.plan.handle, p(self.A if A is None else A),
-                None if B is False else p(self.B if B is None else B),
-                p(self.x_true if x_true is None else x_true), p(self.x_pred if x_pred is None else x_pred),
-                p(weights), float(mu), float(mu_u), p(self.S), p(self.e), p(self.U) if by_products else None,
-                p(self.eps_a) if by_products else None,
-                p(self.V_inv), p(self.eps_b), None, p(self.workspace), _stream()))
+        return 0.0 if self.sharded else mu
+
+    def _exchange_system(self, mu, reduce_packed):
+        """After an assembly of a sharded run: the ranks' camera systems added up (src/sparse_ba.py:189-271
+        are sums over points), the damping of U entering once."""
+        p = _lib.ptr
+        n7 = self.n7
         if reduce_packed:
             # blocks and right-hand-side entries this rank never writes stay zero from allocation
             # (only the entries a band of this width can hold travel: about half of the packed form)
@@ -384,6 +371,41 @@ class DeviceProblem:
             _lib.check(self.lib.sfm_ba_lower_unpack(p(self.tri), n7, float(mu), p(self.S), _stream()))
             self.e.copy_(self.S[n7].view(self.m, 7))
 
+    def assemble_state(self, mu):
+        """Jacobian blocks and Schur assembly in one pass (plans with a fused path): the rows of A of the
+        near points are formed inside the assembly kernel from the camera records and the points and
+        never written; the far points go through the camera-pair kernels inside the same call."""
+        p = _lib.ptr
+        mu_u = self._prepare_system(mu, self.band_sharded)
+        _lib.check(self.lib.sfm_ba_schur_assemble_state(
+            self.plan.handle, p(self.cam_blk), p(self.P), p(self.X), p(self.x_true), float(mu), float(mu_u),
+            p(self.S), p(self.e), p(self.V_inv), p(self.eps_b), p(self.workspace), _stream()))
+        self._exchange_system(mu, self.band_sharded)
+
+    def back_substitute_state(self, update_points=False):
+        """delta_b (and the point update) with the rows of A formed again from the state (the far
+        points' rows are still in the workspace of the assembly)."""
+        p = _lib.ptr
+        _lib.check(self.lib.sfm_ba_back_substitute_state(
+            self.plan.handle, p(self.cam_blk), p(self.V_inv), p(self.eps_b), p(self.delta_a), p(self.delta_b),
+            p(self.X), 1 if update_points else 0, float(self.X_STEP), p(self.workspace), _stream()))
+
+    def assemble(self, mu, weights=None, x_true=None, x_pred=None, A=None, B=None, by_products=True,
+                 reduce_packed=False):
+        """``by_products=False`` skips U and eps_a (the solve needs only S and e): the library then
+        folds the per-camera sums into the camera-pair kernel and makes one pass less over A."""
+        p = _lib.ptr
+        reduce_packed = bool(reduce_packed) and self.band_sharded
+        mu_u = self._prepare_system(mu, reduce_packed)
+        _lib.check(self.lib.sfm_ba_schur_assemble(
+            self.plan.handle, p(self.A if A is None else A),
+            None if B is False else p(self.B if B is None else B),
+            p(self.x_true if x_true is None else x_true), p(self.x_pred if x_pred is None else x_pred),
+            p(weights), float(mu), float(mu_u), p(self.S), p(self.e), p(self.U) if by_products else None,
+            p(self.eps_a) if by_products else None,
+            p(self.V_inv), p(self.eps_b), None, p(self.workspace), _stream()))
+        self._exchange_system(mu, reduce_packed)
+
     def solve(self):
         p = _lib.ptr
         if self._packed_mu is not None:
@@ -393,13 +415,8 @@ class DeviceProblem:
         _lib.check(self.lib.sfm_ba_solve_reduced_banded(p(self.S), self.n7, self.half_bandwidth, p(self.delta_a),
                                                         p(self.chol_ws), p(self.info), _stream()))
 
-    def back_substitute(self, weights=None, update_points=False, A=None, B=None, steps=False):
+    def back_substitute(self, weights=None, update_points=False, A=None, B=None):
         p = _lib.ptr
-        if steps:
-            _lib.check(self.lib.sfm_ba_back_substitute_steps(
-                self.plan.handle, p(self.steps), p(self.V_inv), p(self.eps_b), p(self.delta_a), p(self.delta_b),
-                p(self.X) if update_points else None, float(self.X_STEP), _stream()))
-            return
         _lib.check(self.lib.sfm_ba_back_substitute(
             self.plan.handle, p(self.A if A is None else A), None if B is False else p(self.B if B is None else B),
             p(weights), p(self.V_inv), p(self.eps_b), p(self.delta_a), p(self.delta_b),
@@ -454,17 +471,11 @@ class DeviceProblem:
         mu = self.MU if mu is None else mu
         if not self._blk_fresh:
             self.camera_prepare()
-        if self.from_state and self.plan.fused and mu > 0 and (not self.sharded or self.band_sharded):
-            # plans with runs: the rows of A are formed inside the assembly and the back-substitution
+        if self.from_state and self.plan.fused and mu > 0:
+            # plans with a fused path: the rows of A are formed inside the assembly and the back-substitution
             self.assemble_state(mu)
             self.solve()
             self.back_substitute_state(update_points=True)
-        elif self.plan.fused and self.steps is not None and mu > 0:
-            # plans with runs: A and the residuals never exist in the caller's order
-            self.jacobian_steps()
-            self.assemble(mu, reduce_packed=True, steps=True)
-            self.solve()
-            self.back_substitute(update_points=True, steps=True)
         else:
             self.jacobian(want_B=False)
             self.assemble(mu, by_products=False, reduce_packed=True, B=False)

@@ -64,7 +64,13 @@ class BAProblem:
 
 def _views(rng, m: int, n: int, k, visibility: str) -> tuple[np.ndarray, np.ndarray]:
     """Per-point camera sets.  Returns (pt_idx, cam_idx) of all observations, unsorted."""
-    if np.isscalar(k):
+    if visibility == "tracks":
+        # feature tracks: a point is followed over consecutive frames for a geometrically distributed
+        # length (2 + Geometric, mean k, at most 30 and at most m frames), point ids in the order of
+        # the first observing frame - the order in which an incremental pipeline triangulates them
+        mean = float(k if np.isscalar(k) else k[0])
+        kk = np.minimum(1 + rng.geometric(1.0 / max(mean - 1.0, 1.0), size=n), min(30, m)).astype(np.int64)
+    elif np.isscalar(k):
         kk = np.full(n, int(k), dtype=np.int64)
     else:
         lo, hi = int(k[0]), int(k[1])
@@ -80,7 +86,7 @@ def _views(rng, m: int, n: int, k, visibility: str) -> tuple[np.ndarray, np.ndar
             raise ValueError("a loop needs at least four times as many cameras as views per point")
         start = np.sort(rng.integers(0, m, size=n), kind="stable")
         cams = (start[:, None] + np.arange(kmax)[None, :]) % m
-    elif visibility in ("banded", "closures"):
+    elif visibility in ("banded", "closures", "tracks"):
         # k consecutive cameras from a random start (no wrap-around: S is block-banded).  Point
         # ids ascend with the first observing camera, as they do in the incremental pipeline
         # that feeds the reference's BA: new points are appended to the map when a frame is
@@ -135,6 +141,7 @@ def make_problem(
     K: np.ndarray | None = None,
     base_rotations: np.ndarray | None = None,
     base_centres: np.ndarray | None = None,
+    shuffle_ids: bool = False,
 ) -> BAProblem:
     """Generate a seeded problem.
 
@@ -145,6 +152,8 @@ def make_problem(
     N(0, pixel_noise^2) px, rounded to float32.  The initial state is the ground
     truth perturbed by N(0, point_perturb^2) on points and, for cameras >= 1, a
     left-multiplied Rodrigues N(0, rot_perturb^2) and N(0, trans_perturb^2) on T.
+    ``shuffle_ids``: the point ids are a random relabelling of the order the visibility mode
+    produces (the reference's ``Indices`` takes any numbering, ``/root/reference/src/sparse_ba.py:58-97``).
     """
     rng = np.random.default_rng(seed)
     K = K_DEFAULT.copy() if K is None else np.asarray(K, dtype=np.float64)
@@ -161,10 +170,12 @@ def make_problem(
     T_gt = -np.einsum("mij,mj->mi", R_gt, C_gt)
 
     pt, cam = _views(rng, m, n, k, visibility)
+    if shuffle_ids:
+        pt = np.random.default_rng(seed + 7919).permutation(n)[pt]
     p = observe_and_perturb(rng, K, R_gt, T_gt, X_gt, pt, cam, pixel_noise, point_perturb, rot_perturb,
                             trans_perturb)
     p.visibility = visibility
-    p.meta = dict(m=m, n=n, k=k, seed=seed, pixel_noise=pixel_noise)
+    p.meta = dict(m=m, n=n, k=k, seed=seed, pixel_noise=pixel_noise, shuffle_ids=bool(shuffle_ids))
     return p
 
 
@@ -215,11 +226,14 @@ WORKLOADS = {
 }
 
 
-def make_workload(name: str, visibility: str = "banded", seed: int = 0, points: int | None = None) -> BAProblem:
+def make_workload(name: str, visibility: str = "banded", seed: int = 0, points: int | None = None,
+                  shuffle_ids: bool = False) -> BAProblem:
     m, n, k = WORKLOADS[name]
     if points is not None:
         n = int(points)
-    p = make_problem(m, n, k, visibility=visibility, seed=seed)
+    if visibility == "tracks":
+        k = 6  # mean track length
+    p = make_problem(m, n, k, visibility=visibility, seed=seed, shuffle_ids=shuffle_ids)
     p.meta["workload"] = name
     return p
 

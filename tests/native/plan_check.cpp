@@ -3,8 +3,11 @@
 //   mode 0: every point is seen by k cameras drawn uniformly; mode 1: by k consecutive cameras
 //   around a centre that moves with the point index (banded); mode 2: by k consecutive cameras from
 //   a first camera that ascends with the point index (the order in which an incremental
-//   reconstruction creates points).  Optional sixth argument: 1 / 0 =
-//   the plan must / must not hold runs of the fused assembly.
+//   reconstruction creates points); mode 3: as 2 with the point ids shuffled; mode 4: tracks of
+//   consecutive cameras whose length is geometric (mean 6, up to 30), ids in random order; mode 5: as
+//   2, and every 50th point is seen from one of eight fixed sets of cameras that lie far apart.
+//   Optional sixth argument: 1 / 0 = the plan must / must not hold runs of the fused assembly;
+//   optional seventh: the least share (percent) of the points that must be near.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -31,36 +34,9 @@ static hipError_t host_alloc(void** p, size_t sz) {
     }                                                         \
   } while (0)
 
-int main(int argc, char** argv) {
-  const int m = atoi(argv[1]), n = atoi(argv[2]), k = atoi(argv[3]), mode = atoi(argv[4]), seed = atoi(argv[5]);
-  std::mt19937 rng(seed);
-  std::vector<int32_t> cam, pt;
-  for (int i = 0; i < n; ++i) {
-    std::set<int> cs;
-    const int kk = 2 + (int)(rng() % (unsigned)(k - 1));  // 2..k views
-    if (mode == 0) {
-      while ((int)cs.size() < std::min(kk, m)) cs.insert((int)(rng() % (unsigned)m));
-    } else if (mode == 1) {
-      const int c0 = (int)((int64_t)i * m / n);
-      for (int q = 0; q < kk; ++q) cs.insert(std::min(m - 1, std::max(0, c0 - kk / 2 + q)));
-    } else {
-      const int c0 = (int)((int64_t)i * m / n);
-      for (int q = 0; q < kk; ++q) cs.insert(std::min(m - 1, c0 + q));
-    }
-    for (int c : cs) {
-      cam.push_back(c);
-      pt.push_back(i);
-    }
-  }
-  // caller order: shuffled
+// camera-pair structures of a plan built from the lists (cam, pt)
+static int check_pairs(const sfm_ba_plan* p, const std::vector<int32_t>& cam, const std::vector<int32_t>& pt) {
   const int64_t N = (int64_t)cam.size();
-  for (int64_t i = N - 1; i > 0; --i) {
-    const int64_t j = (int64_t)(rng() % (uint64_t)(i + 1));
-    std::swap(cam[i], cam[j]);
-    std::swap(pt[i], pt[j]);
-  }
-  sfm_ba_plan* p = nullptr;
-  REQUIRE(sfm_ba_plan_create(cam.data(), pt.data(), N, m, n, 0, &p) == SFM_BA_OK);
   const int64_t E = p->n_entries;
   REQUIRE(E == p->n_pair_slots);
   // pair slot -> entry position is a bijection
@@ -104,61 +80,187 @@ int main(int argc, char** argv) {
   REQUIRE(at == E);
   // the records kept behind the last entry are valid rows
   for (int64_t e = E; e < E + sfmba::kPairPad; ++e) REQUIRE(p->d_entries[e].row_a == 0 && p->d_entries[e].row_b == 0);
-  // split blocks: their partials are contiguous, all theirs, and complete
+  // blocks with partial results (split blocks; every block of a far plan): contiguous, all theirs, complete
   int multi = 0;
-  for (int b = 0; b < p->n_blocks; ++b) multi += blk_items[(size_t)b] > 1;
+  for (int b = 0; b < p->n_blocks; ++b) multi += (blk_items[(size_t)b] > 1 || p->force_parts);
   REQUIRE(multi == p->n_multi);
   for (int q = 0; q < p->n_multi; ++q) {
     const int b = p->d_mb_blk[q];
-    REQUIRE(p->d_mb_cnt[q] == blk_items[(size_t)b] && p->d_mb_cnt[q] > 1);
+    REQUIRE(p->d_mb_cnt[q] == blk_items[(size_t)b] && (p->d_mb_cnt[q] > 1 || p->force_parts));
+    REQUIRE(!p->force_parts || b == q);
     for (int i = 0; i < p->d_mb_cnt[q]; ++i) REQUIRE(part_seen[(size_t)(p->d_mb_part[q] + i)] == 1 + b);
   }
   for (int it = 0; it < p->n_pair_items; ++it)
-    REQUIRE((p->d_pit_part[it] < 0) == (blk_items[(size_t)p->d_pit_blk[it]] == 1));
+    REQUIRE((p->d_pit_part[it] < 0) == (blk_items[(size_t)p->d_pit_blk[it]] == 1 && !p->force_parts));
   // every block has entries
   for (int b = 0; b < p->n_blocks; ++b) REQUIRE(blk_items[(size_t)b] >= 1);
-  // runs of the fused assembly: they tile the points, every observation sits at the slot of its
-  // camera in its run's window, every other slot is empty, and the runs are grouped by window
-  if (p->n_runs > 0) {
-    REQUIRE(p->fz_slots >= 4 && p->fz_slots <= 8);
-    REQUIRE(p->fz_group >= 1 && p->fz_pmax >= 8);
-    REQUIRE(p->d_run_pt0[0] == 0 && p->d_run_pt0[p->n_runs] == n);
-    std::vector<int64_t> seen_obs((size_t)N, 0);
-    for (int r = 0; r < p->n_runs; ++r) {
-      const int b = p->d_run_base[r];
-      REQUIRE(p->d_run_pt0[r + 1] > p->d_run_pt0[r] && p->d_run_pt0[r + 1] - p->d_run_pt0[r] <= p->fz_pmax);
-      REQUIRE(b >= 0 && b % p->fz_group == 0);
-      for (int i = p->d_run_pt0[r]; i < p->d_run_pt0[r + 1]; ++i)
-        for (int sl = 0; sl < 8; ++sl) {
-          const int32_t o = p->d_slot_obs[(size_t)i * 8 + sl];
-          if (o < 0) continue;
-          REQUIRE(sl < p->fz_slots && o < N && pt[(size_t)o] == i && cam[(size_t)o] == b + sl);
-          ++seen_obs[(size_t)o];
-        }
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  const int m = atoi(argv[1]), n = atoi(argv[2]), k = atoi(argv[3]), mode = atoi(argv[4]), seed = atoi(argv[5]);
+  std::mt19937 rng(seed);
+  std::vector<int32_t> cam, pt;
+  std::vector<int32_t> label((size_t)n);
+  for (int i = 0; i < n; ++i) label[(size_t)i] = i;
+  if (mode == 3 || mode == 4)
+    for (int i = n - 1; i > 0; --i) std::swap(label[(size_t)i], label[(size_t)(rng() % (unsigned)(i + 1))]);
+  for (int i = 0; i < n; ++i) {
+    std::set<int> cs;
+    const int kk = 2 + (int)(rng() % (unsigned)(k - 1));  // 2..k views
+    if (mode == 0) {
+      while ((int)cs.size() < std::min(kk, m)) cs.insert((int)(rng() % (unsigned)m));
+    } else if (mode == 1) {
+      const int c0 = (int)((int64_t)i * m / n);
+      for (int q = 0; q < kk; ++q) cs.insert(std::min(m - 1, std::max(0, c0 - kk / 2 + q)));
+    } else if (mode == 4) {
+      int len = 2;
+      while (len < 30 && rng() % 6 != 0) ++len;
+      const int c0 = (int)(rng() % (unsigned)m);
+      for (int q = 0; q < len; ++q) cs.insert(std::min(m - 1, c0 + q));
+    } else if (mode == 5 && i % 50 == 7) {
+      const int f = (int)(rng() % 8u);
+      for (int q = 0; q < std::min(kk, 3); ++q) cs.insert((f + q) % m);
+      for (int q = 0; q < std::min(kk, 3); ++q) cs.insert((m / 2 + 3 * f + q) % m);
+    } else {
+      const int c0 = (int)((int64_t)i * m / n);
+      for (int q = 0; q < kk; ++q) cs.insert(std::min(m - 1, c0 + q));
     }
-    for (int64_t o = 0; o < N; ++o) REQUIRE(seen_obs[(size_t)o] == 1);
-    // ranges of pmax points own whole runs
-    REQUIRE(p->n_ranges == (n + p->fz_pmax - 1) / p->fz_pmax);
+    for (int c : cs) {
+      cam.push_back(c);
+      pt.push_back(label[(size_t)i]);
+    }
+  }
+  // caller order: shuffled
+  const int64_t N = (int64_t)cam.size();
+  for (int64_t i = N - 1; i > 0; --i) {
+    const int64_t j = (int64_t)(rng() % (uint64_t)(i + 1));
+    std::swap(cam[i], cam[j]);
+    std::swap(pt[i], pt[j]);
+  }
+  sfm_ba_plan* p = nullptr;
+  REQUIRE(sfm_ba_plan_create(cam.data(), pt.data(), N, m, n, 0, &p) == SFM_BA_OK);
+  if (check_pairs(p, cam, pt)) return 1;
+  // near points of the fused assembly: their positions are tiled by runs, every observation of a near
+  // point sits at the slot of its camera in its run's window, every other slot is empty
+  int64_t near_obs = 0;
+  if (p->n_runs > 0) {
+    REQUIRE(p->fz_slots >= 4 && p->fz_slots <= 8 && p->fz_pmax >= 8);
+    REQUIRE(p->n_near > 0 && p->n_near <= n);
+    REQUIRE(p->d_run_pt0[0] == 0 && p->d_run_pt0[p->n_runs] == p->n_near);
+    std::vector<int> pos_of((size_t)n, -1);
+    for (int q = 0; q < p->n_near; ++q) {
+      const int i = p->d_fz_pt[q];
+      REQUIRE(i >= 0 && i < n && pos_of[(size_t)i] < 0);
+      pos_of[(size_t)i] = q;
+    }
+    std::vector<int64_t> seen_obs((size_t)N, 0);
+    std::set<std::pair<int, int>> need;  // (block, window) pairs the finishing kernel must find
+    std::vector<int> blk_of((size_t)m * m, -1);
+    for (int b = 0; b < p->n_blocks; ++b) blk_of[(size_t)p->d_blk_j[b] * m + p->d_blk_k[b]] = b;
+    int steps = 0;
+    for (int r = 0; r < p->n_runs; ++r) {
+      const int key = p->d_run_key[r];
+      REQUIRE(key >= 0 && key < p->n_keys);
+      REQUIRE(p->d_run_pt0[r + 1] > p->d_run_pt0[r] && p->d_run_pt0[r + 1] - p->d_run_pt0[r] <= p->fz_pmax);
+      REQUIRE(r == 0 || p->d_run_key[r - 1] == key || p->d_run_key[r - 1] == key - 1);
+      steps += (p->d_run_pt0[r + 1] - p->d_run_pt0[r] + 7) / 8;
+      const int32_t* kc = p->d_key_cam + 8 * key;
+      for (int sl = 0; sl < 8; ++sl) {
+        REQUIRE(kc[sl] >= -1 && kc[sl] < m && (sl < p->fz_slots || kc[sl] < 0));
+        const int rc = p->d_run_cam[8 * r + sl];
+        REQUIRE(rc >= 0 && rc < m && (kc[sl] < 0 || rc == kc[sl]));
+      }
+      for (int q = p->d_run_pt0[r]; q < p->d_run_pt0[r + 1]; ++q) {
+        int cams_q[8], nq = 0;
+        for (int sl = 0; sl < 8; ++sl) {
+          const int32_t o = p->d_slot_obs[(size_t)q * 8 + sl];
+          if (o < 0) continue;
+          REQUIRE(sl < p->fz_slots && o < N && pt[(size_t)o] == p->d_fz_pt[q] && cam[(size_t)o] == kc[sl]);
+          ++seen_obs[(size_t)o];
+          cams_q[nq++] = kc[sl];
+        }
+        REQUIRE(nq >= 1);
+        for (int a = 0; a < nq; ++a)
+          for (int b = a; b < nq; ++b) {
+            const int lo = std::min(cams_q[a], cams_q[b]), hi = std::max(cams_q[a], cams_q[b]);
+            REQUIRE(blk_of[(size_t)lo * m + hi] >= 0);
+            need.insert({blk_of[(size_t)lo * m + hi], key});
+          }
+      }
+    }
+    REQUIRE(steps == p->n_steps);
+    for (int64_t o = 0; o < N; ++o) {
+      REQUIRE(seen_obs[(size_t)o] == (pos_of[(size_t)pt[(size_t)o]] >= 0 ? 1 : 0));
+      near_obs += seen_obs[(size_t)o];
+    }
+    // ranges of pmax positions own whole runs
+    REQUIRE(p->n_ranges == (p->n_near + p->fz_pmax - 1) / p->fz_pmax);
     REQUIRE(p->d_rng_run[0] == 0 && p->d_rng_run[p->n_ranges] == p->n_runs);
+    int max_range_runs = 0;
     for (int g = 0; g < p->n_ranges; ++g) {
       REQUIRE(p->d_rng_run[g + 1] > p->d_rng_run[g]);
       REQUIRE(p->d_run_pt0[p->d_rng_run[g]] == g * p->fz_pmax);
+      max_range_runs = std::max(max_range_runs, p->d_rng_run[g + 1] - p->d_rng_run[g]);
     }
-    REQUIRE(p->n_keys == (m - 1) / p->fz_group + 1);
-    REQUIRE(p->d_key_ptr[0] == 0 && p->d_key_ptr[p->n_keys] == p->n_runs);
-    std::vector<char> run_hit((size_t)p->n_runs, 0);
-    for (int q = 0; q < p->n_keys; ++q)
-      for (int i = p->d_key_ptr[q]; i < p->d_key_ptr[q + 1]; ++i) {
-        const int r = p->d_key_run[i];
-        REQUIRE(r >= 0 && r < p->n_runs && !run_hit[(size_t)r] && p->d_run_base[r] == q * p->fz_group);
-        REQUIRE(i == p->d_key_ptr[q] || p->d_key_run[i - 1] < r);
-        run_hit[(size_t)r] = 1;
+    REQUIRE(max_range_runs == p->fz_max_range_runs);
+    // the runs of a window are consecutive; windows differ from their neighbours and hold enough points
+    REQUIRE(p->d_key_run[0] == 0 && p->d_key_run[p->n_keys] == p->n_runs);
+    for (int q = 0; q < p->n_keys; ++q) {
+      REQUIRE(p->d_key_run[q + 1] > p->d_key_run[q]);
+      for (int r = p->d_key_run[q]; r < p->d_key_run[q + 1]; ++r) REQUIRE(p->d_run_key[r] == q);
+      REQUIRE(p->d_run_pt0[p->d_key_run[q + 1]] - p->d_run_pt0[p->d_key_run[q]] >= sfmba::kFzMinWindowPoints);
+      if (q > 0) REQUIRE(memcmp(p->d_key_cam + 8 * q, p->d_key_cam + 8 * (q - 1), 32) != 0);
+    }
+    // entries of the finishing kernel: per block ascending windows, the right cameras at the slots,
+    // and every (block, window) that holds a point's pair of cameras is there
+    REQUIRE(p->d_fb_ptr[0] == 0 && p->d_fb_ptr[p->n_blocks] == p->n_fb);
+    for (int b = 0; b < p->n_blocks; ++b) {
+      for (int e = p->d_fb_ptr[b]; e < p->d_fb_ptr[b + 1]; ++e) {
+        const int ent = p->d_fb_ent[e], key = ent >> 6, sj = (ent >> 3) & 7, sk = ent & 7;
+        REQUIRE(key >= 0 && key < p->n_keys);
+        REQUIRE(p->d_key_cam[8 * key + sj] == p->d_blk_j[b] && p->d_key_cam[8 * key + sk] == p->d_blk_k[b]);
+        REQUIRE(e == p->d_fb_ptr[b] || (p->d_fb_ent[e - 1] >> 6) < key);
+        need.erase({b, key});
       }
+    }
+    REQUIRE(need.empty());
+    // far points: the rest, ascending, with their observations in the caller's relative order
+    REQUIRE(p->n_far == n - p->n_near);
+    for (int q = 0; q < p->n_far; ++q) {
+      REQUIRE(pos_of[(size_t)p->d_far_pt[q]] < 0);
+      REQUIRE(q == 0 || p->d_far_pt[q - 1] < p->d_far_pt[q]);
+    }
+    REQUIRE(p->n_far_obs == N - near_obs);
+    std::vector<int32_t> fcam, fpt;
+    for (int64_t i = 0; i < p->n_far_obs; ++i) {
+      const int32_t o = p->d_far_obs[i];
+      REQUIRE(o >= 0 && o < N && (i == 0 || p->d_far_obs[i - 1] < o));
+      REQUIRE(p->d_far_cam[i] == cam[(size_t)o] && p->d_far_pt[p->d_far_lpt[i]] == pt[(size_t)o]);
+      fcam.push_back(p->d_far_cam[i]);
+      fpt.push_back(p->d_far_lpt[i]);
+    }
+    REQUIRE((p->far != nullptr) == (p->n_far_obs > 0));
+    std::vector<int> far_seen((size_t)p->n_blocks, 0);
+    if (p->far) {
+      const sfm_ba_plan* f = p->far;
+      REQUIRE(f->m == m && f->n == p->n_far && f->n_obs == p->n_far_obs && f->force_parts == 1 && f->n_runs == 0);
+      if (check_pairs(f, fcam, fpt)) return 1;
+      for (int q = 0; q < f->n_blocks; ++q) {
+        const int b = blk_of[(size_t)f->d_blk_j[q] * m + f->d_blk_k[q]];
+        REQUIRE(b >= 0 && p->d_fb_far_part[b] == f->d_mb_part[q] && p->d_fb_far_cnt[b] == f->d_mb_cnt[q]);
+        far_seen[(size_t)b] = 1;
+      }
+    }
+    for (int b = 0; b < p->n_blocks; ++b) REQUIRE(far_seen[(size_t)b] || p->d_fb_far_cnt[b] == 0);
+    REQUIRE(p->ws_total >= p->ws_far + (p->far ? p->far->ws_total : 0));
   }
   if (argc > 6) REQUIRE((p->n_runs > 0) == (atoi(argv[6]) != 0));
-  printf("ok runs=%d slots=%d group=%d pmax=%d ", p->n_runs, p->fz_slots, p->fz_group, p->fz_pmax);
+  if (argc > 7) REQUIRE(100.0 * p->n_near >= (double)atoi(argv[7]) * n);
+  printf("ok runs=%d windows=%d slots=%d pmax=%d near=%d (%.1f%% of the observations) far=%d ", p->n_runs, p->n_keys,
+         p->fz_slots, p->fz_pmax, p->n_near, 100.0 * (double)near_obs / (double)N, p->n_far);
   printf("m=%d n=%d N=%lld blocks=%d entries=%lld items=%d parts=%d half_bandwidth=%d\n", m, n, (long long)N,
-         p->n_blocks, (long long)E, p->n_pair_items, p->n_parts, sfm_ba_plan_half_bandwidth(p));
+         p->n_blocks, (long long)p->n_entries, p->n_pair_items, p->n_parts, sfm_ba_plan_half_bandwidth(p));
   sfm_ba_plan_destroy(p);
   return 0;
 }

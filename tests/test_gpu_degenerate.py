@@ -111,7 +111,9 @@ def test_unobserved_point_on_a_hinted_plan(vis, k, where):
     mu = 0.5
     ref = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true)
     hol = DeviceProblem(p.K, p.R, p.T, X_gap, p.cam_idx, pt_gap, p.x_true, n_cams=p.m, check=False)
-    assert hol.n == p.n + 1 and hol.plan.fused == 0
+    assert hol.n == p.n + 1
+    # the point nobody names goes with the far points of the plan
+    assert hol.plan.fused == 0 or gap in hol.plan.read("far_pt")
     ref.plan.set_fused(0)
     out = []
     for prob in (ref, hol):
@@ -133,6 +135,21 @@ def test_unobserved_point_on_a_hinted_plan(vis, k, where):
     assert np.allclose(V1[gap].reshape(3, 3), np.identity(3) / mu, rtol=1e-14, atol=0)
     assert not b1[gap].any() and not db1[gap].any()
     assert np.max(np.abs(da0 - da1)) <= 1e-9 * np.max(np.abs(da0))
+    if hol.plan.fused and hol.from_state:
+        # the same through the fused path: the point's V_i^-1 = I / mu, eps_b = delta_b = 0 come from the
+        # far points' kernels (or, when no far point has an observation, from a kernel of their own)
+        hol.sys.zero_()
+        hol.V_inv.fill_(float("nan")); hol.eps_b.fill_(float("nan")); hol.delta_b.fill_(float("nan"))
+        hol.assemble_state(mu)
+        hol.solve()
+        hol.back_substitute_state()
+        S2, V2, b2, db2 = (torch.tril(hol.S[:7 * p.m]).cpu().numpy(), hol.V_inv.cpu().numpy(), hol.eps_b.cpu().numpy(),
+                           hol.delta_b.cpu().numpy())
+        assert np.max(np.abs(S0 - S2)) <= 1e-12 * np.max(np.abs(S0))
+        assert np.max(np.abs(V0 - V2[keep])) <= 1e-11 * np.max(np.abs(V0))
+        assert np.allclose(V2[gap].reshape(3, 3), np.identity(3) / mu, rtol=1e-14, atol=0)
+        assert not b2[gap].any() and not db2[gap].any()
+        assert np.max(np.abs(db0 - db2[keep])) <= 1e-7 * np.max(np.abs(db0))
     assert np.max(np.abs(db0 - db1[keep])) <= 1e-9 * np.max(np.abs(db0))
 
 

@@ -68,20 +68,3 @@ def test_loop_visibility():
     assert k.min() >= 4 and k.max() <= 6
     with pytest.raises(ValueError):
         synthetic.make_problem(12, 100, 4, visibility="loop")
-
-
-def test_point_spans():
-    from sfm_amd.split import MAX_WINDOW, point_spans
-
-    cam = np.array([0, 1, 1, 3, 4, 9])
-    pt = np.array([0, 0, 1, 2, 1, 1])
-    lo, hi = point_spans(cam, pt, 4)
-    assert lo.tolist() == [0, 1, 3, -1] and hi.tolist() == [1, 9, 3, -1]
-    # a point is far when its cameras do not fit one window of the fused assembly
-    assert ((hi - lo + 1) > MAX_WINDOW).tolist() == [False, True, False, False]
-    p = synthetic.make_problem(40, 3000, (4, 6), visibility="loop", seed=5)
-    lo, hi = point_spans(p.cam_idx, p.pt_idx, p.n)
-    far = (hi - lo + 1) > MAX_WINDOW
-    # the points of a closed loop that wrap around the end of the sequence, and only those
-    assert 0 < far.sum() < p.n // 5
-    assert np.all(hi[far] >= 40 - 6) and np.all(lo[far] <= 5)

@@ -1,7 +1,9 @@
 """Host visibility-plan builder checked without a GPU: tests/native/plan_check.cpp compiles the
 builder with device allocation replaced by host memory and verifies the invariants the kernels
 rely on (pair slots <-> entries bijection, work items tile the entry list and stay inside their
-camera-pair block, partial results of split blocks contiguous and complete, valid padding)."""
+camera-pair block, partial results of split blocks contiguous and complete, valid padding; near
+points tiled by runs with every observation at the slot of its camera, far points and their plan,
+the finishing kernel's entries covering every (block, window) a near point contributes to)."""
 import os
 import subprocess
 
@@ -20,15 +22,19 @@ def checker(tmp_path_factory):
 
 
 @pytest.mark.parametrize("args", [
-    (20, 2000, 6, 0, 1, 0),   # uniform visibility: every camera pair is a block, no runs
-    (20, 2000, 6, 1, 1, 0),   # banded around a moving centre: first cameras alternate, no runs
-    (20, 2000, 6, 2, 1, 1),   # first camera ascends: runs of the fused assembly in windows of 6 cameras
-    (60, 30000, 8, 2, 5, 1),  # windows of 8 cameras
-    (90, 30000, 7, 2, 6, 1),  # windows of 7
-    (12, 5000, 3, 2, 7, 1),   # two first-cameras per window of 4
-    (200, 100000, 9, 1, 2),   # split blocks
+    (50, 20000, 8, 0, 1, 0),        # uniform visibility: camera sets do not repeat, every point is far, no fused path
+    (20, 2000, 6, 0, 1),            # few cameras, uniform: some camera sets repeat often enough for windows of their own
+    (20, 2000, 6, 1, 1, 1, 100),    # banded around a moving centre
+    (20, 2000, 6, 2, 1, 1, 100),    # first camera ascends: windows of 6 cameras
+    (60, 30000, 8, 2, 5, 1, 100),   # windows of 8 cameras
+    (90, 30000, 7, 2, 6, 1, 100),   # windows of 7
+    (12, 5000, 3, 2, 7, 1, 100),    # windows of 4, several first-cameras per window
+    (200, 100000, 9, 1, 2, 1, 80),  # split blocks; points with 9 cameras are far
     (3, 50, 3, 0, 3),
-    (40, 400, 30, 0, 4),      # many views per point
+    (40, 400, 30, 0, 4, 0),         # many views per point
+    (90, 30000, 7, 3, 6, 1, 100),   # banded with shuffled point ids
+    (200, 100000, 8, 4, 2, 1, 70),  # tracks of geometric length up to 30, ids in random order
+    (100, 50000, 6, 5, 3, 1, 99),   # distant camera sets shared by many points: windows of their own
 ])
 def test_plan_invariants(checker, args):
     out = subprocess.run([checker] + [str(a) for a in args], capture_output=True, text=True)
