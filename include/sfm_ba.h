@@ -198,15 +198,22 @@ int sfm_ba_schur_assemble(const sfm_ba_plan* plan, const double* d_A, const doub
  * (src/bundle_adjustment.py:22-67, src/jacobian.py:21-220, src/utils.py:8-11) - are formed inside
  * the assembly kernel from the prepared camera records (sfm_ba_camera_prepare), the projection
  * matrices d_P [m,12], the points d_X [n,3] and d_x_true [N,2], and consumed there by calc_V_inv ...
- * calc_e (src/sparse_ba.py:147-271): A, B and x_pred are never written to memory.  Outputs as
- * sfm_ba_schur_assemble writes them without by-products (d_S lower triangle and row 7m, d_e, d_V_inv,
- * d_eps_b); mu > 0.  The rows agree with those sfm_ba_jacobian writes to a few units in the last
+ * calc_e (src/sparse_ba.py:147-271): for the near points A, B and x_pred are never written to memory
+ * (the rows of the far points' observations go to the workspace and through the camera-pair kernels).
+ * Outputs as sfm_ba_schur_assemble writes them without by-products (d_S lower triangle and row 7m, d_e,
+ * d_V_inv, d_eps_b); mu > 0.  The rows agree with those sfm_ba_jacobian writes to a few units in the last
  * place (one reciprocal per quotient rule instead of a division per entry).
+ *   d_cam_ssq [m] out, may be NULL: per camera the sum of squared residuals of its observations at this
+ *   state - the sums `compute_reprojection_error_total` (src/bundle_adjustment.py:9-19) takes the roots
+ *   of, a by-product of the residuals the kernels form anyway: sfm_ba_cost_finish(d_cam_ssq, ...) then
+ *   gives the cost of the state the system was assembled at without a pass of its own (equal to
+ *   sfm_ba_cost's to rounding; the sums are associated differently).  Entries of cameras without
+ *   observations are not written (zero the array once).
  * ---------------------------------------------------------------------------------------- */
 int sfm_ba_plan_state_path(const sfm_ba_plan* plan);
 int sfm_ba_schur_assemble_state(const sfm_ba_plan* plan, const double* d_cam_blk, const double* d_P, const double* d_X,
                                 const double* d_x_true, double mu, double mu_u, double* d_S, double* d_e,
-                                double* d_V_inv, double* d_eps_b, void* d_workspace, void* stream);
+                                double* d_V_inv, double* d_eps_b, double* d_cam_ssq, void* d_workspace, void* stream);
 /* calc_delta_b (src/sparse_ba.py:279-290) the same way: the rows of A are formed again from the camera
  * records and d_X (the state the system was assembled at: call it before the cameras are updated).
  * d_workspace: the workspace the preceding sfm_ba_schur_assemble_state call on this state used (it

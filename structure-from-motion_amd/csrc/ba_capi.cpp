@@ -51,11 +51,11 @@ int sfm_ba_plan_state_path(const sfm_ba_plan* plan) { return plan && fz_state_ap
 
 int sfm_ba_schur_assemble_state(const sfm_ba_plan* plan, const double* d_cam_blk, const double* d_P, const double* d_X,
                                 const double* d_x_true, double mu, double mu_u, double* d_S, double* d_e,
-                                double* d_V_inv, double* d_eps_b, void* d_workspace, void* stream) {
+                                double* d_V_inv, double* d_eps_b, double* d_cam_ssq, void* d_workspace, void* stream) {
   if (!plan || !d_cam_blk || !d_P || !d_X || !d_x_true || !d_V_inv || !d_eps_b || !d_workspace) return SFM_BA_EINVAL;
   if (!fz_state_applies(plan) || !(mu > 0.0) || !(mu_u >= 0.0)) return SFM_BA_EINVAL;
-  return launch_assemble_state(plan, d_cam_blk, d_P, d_X, d_x_true, mu, mu_u, d_S, d_e, d_V_inv, d_eps_b, d_workspace,
-                               static_cast<hipStream_t>(stream));
+  return launch_assemble_state(plan, d_cam_blk, d_P, d_X, d_x_true, mu, mu_u, d_S, d_e, d_V_inv, d_eps_b, d_cam_ssq,
+                               d_workspace, static_cast<hipStream_t>(stream));
 }
 
 int sfm_ba_back_substitute_state(const sfm_ba_plan* plan, const double* d_cam_blk, const double* d_V_inv,

@@ -14,7 +14,8 @@ constexpr int kCamChunk = 1024;    // observations per per-camera work item
 constexpr int kCamThreads = 128;   // threads of a per-camera work item
 constexpr int kPairChunk = 512;   // (obs, obs) entries per camera-pair work item (one wave each)
 constexpr int kPairPad = 64;
-constexpr int kPairPartStride = 56;  // doubles per partial result of a split block: 7x7 block + e_j        // valid records / T rows kept behind the last entry
+constexpr int kPairPartStride = 64;  // doubles per partial result of a split block: 7x7 block, e_j (49..55), the
+                                     // camera's sum of squared residuals (56); diagonal blocks only fill 49..56
 
 // Fused point-major assembly.  The plan sorts the points it can handle this way ("near" points) by the
 // window of cameras they are seen from and walks them by position in that order:
@@ -31,8 +32,8 @@ constexpr int kFzLanesPerPoint = 8;  // lanes (= slot positions of the table) pe
 constexpr int kFzMaxPmax = 1024;     // longest range of points one wave walks (and with it: runs per range)
 constexpr int kFzMaxRunsPerRange = 256;  // what the kernel that forms A itself keeps of a range's run boundaries
 constexpr int kFzMinWindowPoints = 4;    // a window with fewer points is not worth a partial result of its own
-constexpr int kFzSlotSums = 35;      // per-camera-slot sums behind a partial's tiles: 28 (upper triangle of
-                                     // sum A^T A) + 7 (sum A^T g); 7 more per extra row
+constexpr int kFzSlotSums = 36;      // per-camera-slot sums behind a partial's tiles: 28 (upper triangle of
+                                     // sum A^T A) + 7 (sum A^T g) + 1 (sum |eps|^2); 7 more per extra row
 // Cameras per window for a plan, from two histograms over the points with at most 8 cameras: obs_by_k[v]
 // / obs_by_span[v] = observations of the points with v cameras / with a camera span of v (spans
 // beyond 8: not counted).  The smallest width that keeps 98 % of what a width of 8 would keep; measured
@@ -105,8 +106,8 @@ __host__ __device__ inline int fz_slot_of(const int32_t desc[8], int32_t c) {
 __host__ __device__ inline int fz_row_tiles(int slots) { return slots <= 4 ? 2 : (slots <= 7 ? 3 : 4); }
 __host__ __device__ inline int fz_extra_rows(int slots) { return slots == 7 ? 1 : 0; }
 // doubles of one partial result: lower-triangle tiles (16 x 16), then the per-slot sums as
-// [value][slot] (value i of slot s at 8 i + s: 28 of U, 7 of e, 7 per extra row), rounded up to whole
-// 256-byte units
+// [value][slot] (value i of slot s at 8 i + s: 28 of U, 7 of e, the squared residuals, 7 per extra
+// row), rounded up to whole 256-byte units
 __host__ __device__ constexpr int64_t fz_part_stride_c(int tiles, int extra) {
   return (int64_t)(tiles * (tiles + 1) / 2) * 256 + (((kFzSlotSums + 7 * extra) * 8 + 31) & ~31);
 }
@@ -197,7 +198,7 @@ struct sfm_ba_plan {
   int32_t force_parts = 0;        // this plan is the far plan of another: every block writes partial results
   int64_t device_bytes = 0;
   // workspace section offsets (bytes)
-  int64_t ws_g = 0, ws_T = 0, ws_campart = 0, ws_spart = 0, ws_fpart = 0, ws_fkey = 0, ws_fzero = 0, ws_far_A = 0,
+  int64_t ws_g = 0, ws_T = 0, ws_q = 0, ws_campart = 0, ws_spart = 0, ws_fpart = 0, ws_fkey = 0, ws_fzero = 0, ws_far_A = 0,
           ws_far_xt = 0, ws_far_xp = 0, ws_far = 0, ws_total = 0;
 };
 
@@ -260,7 +261,7 @@ int launch_calc_W_Y(const sfm_ba_plan* p, const double* A, const double* B, cons
 int launch_add_diagonal(double* S, int n7, double mu, hipStream_t st);
 bool fz_state_applies(const sfm_ba_plan* p);
 int launch_assemble_state(const sfm_ba_plan* p, const double* blk, const double* P, const double* X, const double* xt,
-                          double mu, double mu_u, double* S, double* e, double* Vinv, double* eps_b, void* ws,
+                          double mu, double mu_u, double* S, double* e, double* Vinv, double* eps_b, double* ssq, void* ws,
                           hipStream_t st);
 int launch_back_substitute_state(const sfm_ba_plan* p, const double* blk, const double* Vinv, const double* eps_b,
                                  const double* da, double* db, double* X, int update, double x_step, void* ws,

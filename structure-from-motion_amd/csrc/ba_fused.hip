@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
   d4_t acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = d4_t{0.0, 0.0, 0.0, 0.0};
-  double u[28], ev[7], xa[E > 0 ? E : 1][7];
+  double u[28], ev[7], ssq = 0.0, xa[E > 0 ? E : 1][7];
 #pragma unroll
   for (int i = 0; i < 28; ++i) u[i] = 0.0;
 #pragma unroll
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
   d4_t acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = d4_t{0.0, 0.0, 0.0, 0.0};
-  double u[28], ev[7], xa[E > 0 ? E : 1][7];
+  double u[28], ev[7], ssq = 0.0, xa[E > 0 ? E : 1][7];
 #pragma unroll
   for (int i = 0; i < 28; ++i) u[i] = 0.0;
 #pragma unroll
@@ -705,10 +705,12 @@ __global__ __launch_bounds__(64) void k_fused_finish(const int32_t* __restrict__
                                                      const int32_t* __restrict__ fb_far_part,
                                                      const int32_t* __restrict__ fb_far_cnt, int slots,
                                                      const double* __restrict__ kpart, const double* __restrict__ far_part,
-                                                     double mu_u, int m, double* __restrict__ S, double* __restrict__ e_out) {
+                                                     double mu_u, int m, double* __restrict__ S, double* __restrict__ e_out,
+                                                     double* __restrict__ ssq_out) {
+  // threads 0..48: the 7 x 7 block; 49..55: e_j, 56: the camera's sum of squared residuals (diagonal blocks)
   const int t = threadIdx.x;
   const int j = blk_j[blockIdx.x], k = blk_k[blockIdx.x];
-  if (t >= 56 || (t >= 49 && j != k)) return;
+  if (t >= 57 || (t >= 49 && j != k)) return;
   const int T = fz_row_tiles(slots), E = fz_extra_rows(slots);
   const int nt = T * (T + 1) / 2;
   const int64_t stride = fz_part_stride_c(T, E);
@@ -735,16 +737,17 @@ __global__ __launch_bounds__(64) void k_fused_finish(const int32_t* __restrict__
         const int ti = row >> 4, tj = col >> 4;
         v = pb[(ti * (ti + 1) / 2 + tj) * 256 + (row & 15) * 16 + (col & 15)];
       } else {
-        v = pb[nt * 256 + (35 + 7 * (row - 16 * T) + col % 7) * 8 + col / 7];
+        v = pb[nt * 256 + (kFzSlotSums + 7 * (row - 16 * T) + col % 7) * 8 + col / 7];
       }
       if (j == k) v = pb[nt * 256 + uidx * 8 + sj] - v;
       sum += v;
     } else {
-      sum += pb[nt * 256 + (28 + (t - 49)) * 8 + sj];
+      sum += pb[nt * 256 + (28 + (t - 49)) * 8 + sj];  // (t = 56: value 35, the squared residuals)
     }
   }
   // the far points' share: sum A_j^T T A_k over their entries of the pair, which on the diagonal holds
-  // sum Y W^T - U_j (see k_point), and sum A^T g in slots 49..55 of a diagonal block's partials
+  // sum Y W^T - U_j (see k_point), and sum A^T g in slots 49..55, sum |eps|^2 in slot 56 of a diagonal
+  // block's partials
   {
     const int cnt = fb_far_cnt[blockIdx.x];
     const double* fp = far_part + (int64_t)fb_far_part[blockIdx.x] * kPairPartStride + t;
@@ -753,7 +756,9 @@ __global__ __launch_bounds__(64) void k_fused_finish(const int32_t* __restrict__
     if (cnt > 0) sum = (t >= 49 || j != k) ? sum + far : sum - far;
   }
   const int64_t ld = 7 * (int64_t)m;
-  if (t >= 49) {
+  if (t == 56) {
+    if (ssq_out) ssq_out[j] = sum;
+  } else if (t >= 49) {
     S[ld * ld + 7 * j + (t - 49)] = sum;
     if (e_out) e_out[7 * j + (t - 49)] = sum;
   } else if (j == k) {
@@ -822,8 +827,8 @@ static void fz_print_stamps() {
 }
 #endif
 // reduce and finish shared by the two kernels that produce the partial results
-static int launch_fused_tail(const sfm_ba_plan* p, double mu_u, double* S, double* e, double* part, double* kpart,
-                             const double* far_part, hipStream_t st);
+static int launch_fused_tail(const sfm_ba_plan* p, double mu_u, double* S, double* e, double* ssq, double* part,
+                             double* kpart, const double* far_part, hipStream_t st);
 
 bool fz_state_applies(const sfm_ba_plan* p) {
   return p->n_runs > 0 && p->fz_enabled && p->fz_max_range_runs <= kFzMaxRunsPerRange;
@@ -851,7 +856,7 @@ static const double* far_partials(const sfm_ba_plan* p, const char* ws) {
 }
 
 int launch_assemble_state(const sfm_ba_plan* p, const double* blk, const double* P, const double* X, const double* xt,
-                          double mu, double mu_u, double* S, double* e, double* Vinv, double* eps_b, void* ws,
+                          double mu, double mu_u, double* S, double* e, double* Vinv, double* eps_b, double* ssq, void* ws,
                           hipStream_t st) {
   if (!fz_state_applies(p)) return SFM_BA_EINVAL;
   char* base = static_cast<char*>(ws);
@@ -913,7 +918,7 @@ int launch_assemble_state(const sfm_ba_plan* p, const double* blk, const double*
   const int rc = check_launch_fz("k_fused_state");
   if (rc) return rc;
   if (!S) return SFM_BA_OK;
-  return launch_fused_tail(p, mu_u, S, e, part, kpart, far_partials(p, base), st);
+  return launch_fused_tail(p, mu_u, S, e, ssq, part, kpart, far_partials(p, base), st);
 }
 
 int launch_back_substitute_state(const sfm_ba_plan* p, const double* blk, const double* Vinv, const double* eps_b,
@@ -988,11 +993,11 @@ int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* x
   int rc = check_launch_fz("k_fused_runs");
   if (rc) return rc;
   if (!S) return SFM_BA_OK;
-  return launch_fused_tail(p, mu_u, S, e, part, kpart, far_partials(p, base), st);
+  return launch_fused_tail(p, mu_u, S, e, nullptr, part, kpart, far_partials(p, base), st);
 }
 
-static int launch_fused_tail(const sfm_ba_plan* p, double mu_u, double* S, double* e, double* part, double* kpart,
-                             const double* far_part, hipStream_t st) {
+static int launch_fused_tail(const sfm_ba_plan* p, double mu_u, double* S, double* e, double* ssq, double* part,
+                             double* kpart, const double* far_part, hipStream_t st) {
   const int64_t stride = fz_part_stride(p->fz_slots);
   {
     ProfScope ps(KID_FUSED_REDUCE, st);
@@ -1003,7 +1008,7 @@ static int launch_fused_tail(const sfm_ba_plan* p, double mu_u, double* S, doubl
   if (p->n_blocks > 0) {
     ProfScope ps(KID_FUSED_FINISH, st);
     hipLaunchKernelGGL(k_fused_finish, dim3(p->n_blocks), dim3(64), 0, st, p->d_blk_j, p->d_blk_k, p->d_fb_ptr,
-                       p->d_fb_ent, p->d_fb_far_part, p->d_fb_far_cnt, p->fz_slots, kpart, far_part, mu_u, p->m, S, e);
+                       p->d_fb_ent, p->d_fb_far_part, p->d_fb_far_cnt, p->fz_slots, kpart, far_part, mu_u, p->m, S, e, ssq);
   }
   return check_launch_fz("k_fused_finish");
 }

@@ -311,6 +311,7 @@ __device__ __noinline__ void pinv_sym3(double a00, double a01, double a02, doubl
 struct ObsTerms {
   double bb[6], bp[6], we[2];
   double w00, w01, w10, w11;
+  double e0, e1;  // the residual itself
 };
 
 __device__ inline void obs_terms(int64_t pos, const double* __restrict__ A, const double* __restrict__ B,
@@ -339,6 +340,8 @@ __device__ inline void obs_terms(int64_t pos, const double* __restrict__ A, cons
   }
   o.we[0] = o.w00 * e0 + o.w01 * e1;
   o.we[1] = o.w10 * e0 + o.w11 * e1;
+  o.e0 = e0;
+  o.e1 = e1;
 }
 
 // V^-1 (00 01 02 11 12 22) of the damped point block from the sums a[0..5] = B^T w B.
@@ -368,7 +371,7 @@ __device__ __noinline__ void point_long(int t, int p0, int pid, int s0, int ns, 
                                         const double* __restrict__ xt, const double* __restrict__ xpred,
                                         const double* __restrict__ wgt, double mu, int fold_u,
                                         double* __restrict__ Vinv, double* __restrict__ eps_b, double* __restrict__ g,
-                                        double* __restrict__ T, double* sRed /* 256 x 9 */) {
+                                        double* __restrict__ qsq, double* __restrict__ T, double* sRed /* 256 x 9 */) {
   double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int s = t; s < ns; s += 256) {
     ObsTerms o;
@@ -416,6 +419,7 @@ __device__ __noinline__ void point_long(int t, int p0, int pid, int s0, int ns, 
     obs_terms(pos, A, B, xt, xpred, wgt, o);
     st2(g + 2 * pos, o.we[0] - (o.bp[0] * z0 + o.bp[1] * z1 + o.bp[2] * z2),
         o.we[1] - (o.bp[3] * z0 + o.bp[4] * z1 + o.bp[5] * z2));
+    st2(qsq + 2 * pos, o.e0 * o.e0 + o.e1 * o.e1, 0.0);
     const double h00 = o.bp[0] * iv[0] + o.bp[1] * iv[1] + o.bp[2] * iv[2];
     const double h01 = o.bp[0] * iv[1] + o.bp[1] * iv[3] + o.bp[2] * iv[4];
     const double h02 = o.bp[0] * iv[2] + o.bp[1] * iv[4] + o.bp[2] * iv[5];
@@ -455,7 +459,8 @@ __global__ __launch_bounds__(256) void k_point(
     const int32_t* __restrict__ pair_entry, const double* __restrict__ A,
     const double* __restrict__ B, const double* __restrict__ xt, const double* __restrict__ xpred,
     const double* __restrict__ wgt, double mu, int fold_u, double* __restrict__ Vinv,
-    double* __restrict__ eps_b, double* __restrict__ g, double* __restrict__ T) {
+    double* __restrict__ eps_b, double* __restrict__ g, double* __restrict__ qsq, double* __restrict__ T) {
+  // qsq: per observation {squared residual, 0}, what the camera-pair kernel adds up per camera for the cost
   __shared__ double sBp[kGroupSlots * 6];
   __shared__ double sCon[kGroupSlots * 9];
   __shared__ int sPtr[kGroupSlots + 1];
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(256) void k_point(
   const int ns = sPtr[np] - s0;
   if (ns > kGroupSlots) {  // one point with more observations than lanes (same for the whole workgroup)
     point_long(t, p0, pt_map ? pt_map[p0] : p0, s0, ns, perm, tp_ptr, pair_entry, A, B, xt, xpred, wgt, mu, fold_u, Vinv,
-               eps_b, g, T, sCon);
+               eps_b, g, qsq, T, sCon);
     return;
   }
   if (t < np)
@@ -493,6 +498,7 @@ __global__ __launch_bounds__(256) void k_point(
     }
     const double2 xa = ld2(xt + 2 * (int64_t)pos), xb = ld2(xpred + 2 * (int64_t)pos);
     const double e0 = xa.x - xb.x, e1 = xa.y - xb.y;
+    st2(qsq + 2 * (int64_t)pos, e0 * e0 + e1 * e1, 0.0);
     if (wgt) {
       const double* wp = wgt + 4 * (int64_t)pos;
       w00 = wp[0]; w01 = wp[1]; w10 = wp[2]; w11 = wp[3];
@@ -759,9 +765,11 @@ __global__ __launch_bounds__(64) void k_pair_blocks(
     const int32_t* __restrict__ pit_end, const int32_t* __restrict__ pit_part,
     const int32_t* __restrict__ blk_j, const int32_t* __restrict__ blk_k,
     const PairEntry* __restrict__ ent, const double* __restrict__ A, const double* __restrict__ gT,
-    unsigned t_off, int fold_u, const double* __restrict__ cam_part, const int32_t* __restrict__ cam_item_ptr,
-    double mu_u, int m, double* __restrict__ S, double* __restrict__ e_out, double* __restrict__ spart) {
-  // gT: start of the buffer that holds g [N][2] (at byte 0) and T [pairs][4] (at byte t_off).
+    unsigned t_off, unsigned q_off, int fold_u, const double* __restrict__ cam_part,
+    const int32_t* __restrict__ cam_item_ptr, double mu_u, int m, double* __restrict__ S, double* __restrict__ e_out,
+    double* __restrict__ ssq_out, double* __restrict__ spart) {
+  // gT: start of the buffer that holds g [N][2] (at byte 0), T [pairs][4] (at byte t_off) and the squared
+  // residuals [N][2] (at byte q_off).
   // fold_u: the self pairs carry U_j (see k_point) and the diagonal blocks also sum e_j = A^T g
   // one LDS object for row images and record slots
   __shared__ __attribute__((aligned(16))) double lds[(kPairRing * kPairImgB + kPairERing * 1024) / 8];
@@ -805,11 +813,13 @@ __global__ __launch_bounds__(64) void k_pair_blocks(
     // (records past the item's end belong to the next block, whose second field is a row of A, not
     // an entry of g: those lanes fetch g[0], which is never used)
     if (with_e && lane >= 32 && lane < 48) toff = i0 + (lane - 32) < end ? (unsigned)er[2 * (lane - 32) + 1] : 0u;
+    // lanes 48..63 of a diagonal block: the squared residuals of the same 16 observations
+    if (with_e && lane >= 48) toff = q_off + (i0 + (lane - 48) < end ? (unsigned)er[2 * (lane - 48) + 1] : 0u);
     dma16x5(A, (unsigned)ea.x + 16u * c0, (unsigned)eb.x + 16u * c1, (unsigned)(diag ? ea.x : ea.y) + 16u * c0,
             (unsigned)(diag ? eb.x : eb.y) + 16u * c1, gT, toff, base);
   };
   double acc0[7] = {0, 0, 0, 0, 0, 0, 0}, acc1[7] = {0, 0, 0, 0, 0, 0, 0};
-  double e0 = 0.0, e1 = 0.0;
+  double e0 = 0.0, e1 = 0.0, sq = 0.0;
   // `tail`: the step may reach past the item's last entry (only the last step can)
   auto consume = [&](int q, bool tail) {
     const int i0 = beg + kPairStep * q;
@@ -828,6 +838,8 @@ __global__ __launch_bounds__(64) void k_pair_blocks(
       if (dead) gv = make_double2(0.0, 0.0);
       e0 = fma(b10, gv.y, fma(b0.x, gv.x, e0));
       e1 = fma(b11, gv.y, fma(b0.y, gv.x, e1));
+      // (every lane of the entry's group reads it; lane h = 0 of the group is the one that counts)
+      sq += dead ? 0.0 : ba[512 + 96 + 2 * g];
     }
     double a[14];
 #pragma unroll
@@ -876,6 +888,7 @@ __global__ __launch_bounds__(64) void k_pair_blocks(
     for (int sft = 4; sft < 64; sft <<= 1) {
       e0 += __shfl_xor(e0, sft);
       e1 += __shfl_xor(e1, sft);
+      sq += __shfl_xor(sq, sft);
     }
   }
   if (g != 0) return;
@@ -891,6 +904,7 @@ __global__ __launch_bounds__(64) void k_pair_blocks(
     if (with_e) {
       o[49 + 2 * h] = e0;
       if (ncol == 2) o[49 + 2 * h + 1] = e1;
+      if (h == 0) o[56] = sq;
     }
     return;
   }
@@ -902,6 +916,7 @@ __global__ __launch_bounds__(64) void k_pair_blocks(
       S[ld * ld + 7 * j + 2 * h + cs] = ev;
       if (e_out) e_out[7 * j + 2 * h + cs] = ev;
     }
+    if (h == 0 && ssq_out) ssq_out[j] = sq;
   }
   for (int cs = 0; cs < ncol; ++cs) {
     const int c = 2 * h + cs;
@@ -933,9 +948,9 @@ __global__ __launch_bounds__(64) void k_pair_finish(
     const int32_t* __restrict__ mb_cnt, const int32_t* __restrict__ blk_j,
     const int32_t* __restrict__ blk_k, const double* __restrict__ spart,
     const double* __restrict__ cam_part, const int32_t* __restrict__ cam_item_ptr, double mu_u, int m,
-    int fold_u, double* __restrict__ S, double* __restrict__ e_out) {
+    int fold_u, double* __restrict__ S, double* __restrict__ e_out, double* __restrict__ ssq_out) {
   const int t = threadIdx.x;
-  if (t >= kPairPartStride) return;
+  if (t > 56) return;
   const int b = mb_blk[blockIdx.x];
   const int p0 = mb_part[blockIdx.x], cnt = mb_cnt[blockIdx.x];
   const int j = blk_j[b], k = blk_k[b];
@@ -943,6 +958,10 @@ __global__ __launch_bounds__(64) void k_pair_finish(
   double a = 0.0;
   for (int i = 0; i < cnt; ++i) a += spart[(int64_t)(p0 + i) * kPairPartStride + t];
   const int64_t ld = 7 * (int64_t)m;
+  if (t == 56) {
+    if (ssq_out) ssq_out[j] = a;  // the camera's squared residuals (slot 56)
+    return;
+  }
   if (t >= 49) {
     // e_j of a diagonal block (slots 49..55 of its partials)
     S[ld * ld + 7 * j + (t - 49)] = a;
@@ -1346,6 +1365,7 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
   char* base = static_cast<char*>(ws);
   double* g = reinterpret_cast<double*>(base + p->ws_g);
   double* T = reinterpret_cast<double*>(base + p->ws_T);
+  double* qsq = reinterpret_cast<double*>(base + p->ws_q);
   double* campart = reinterpret_cast<double*>(base + p->ws_campart);
   double* spart = reinterpret_cast<double*>(base + p->ws_spart);
   // Callers that want none of the per-camera by-products (U, eps_a, the all-reduce records) get
@@ -1359,7 +1379,7 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
     {
     ProfScope ps(KID_POINT, st);
     hipLaunchKernelGGL(k_point, dim3(p->n_groups), dim3(256), 0, st, static_cast<const int32_t*>(nullptr), p->d_grp_pt,
-                       p->d_pt_ptr, p->d_perm, p->d_tp_ptr, p->d_pair_entry, A, B, xt, xp, w, mu, fold_u, Vinv, eps_b, g, T);
+                       p->d_pt_ptr, p->d_perm, p->d_tp_ptr, p->d_pair_entry, A, B, xt, xp, w, mu, fold_u, Vinv, eps_b, g, qsq, T);
   }
     int rc = check_launch("k_point");
     if (rc) return rc;
@@ -1388,8 +1408,8 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
     ProfScope ps(KID_PAIR_BLOCKS, st);
     hipLaunchKernelGGL(k_pair_blocks, dim3(p->n_pair_items), dim3(64), 0, st, p->n_pair_items,
                        p->d_pit_blk, p->d_pit_beg, p->d_pit_end, p->d_pit_part, p->d_blk_j, p->d_blk_k,
-                       p->d_entries, A, g, (unsigned)(p->ws_T - p->ws_g), fold_u, campart, p->d_cam_item_ptr, mu_u,
-                       p->m, S, e, spart);
+                       p->d_entries, A, g, (unsigned)(p->ws_T - p->ws_g), (unsigned)(p->ws_q - p->ws_g), fold_u, campart,
+                       p->d_cam_item_ptr, mu_u, p->m, S, e, static_cast<double*>(nullptr), spart);
   }
     rc = check_launch("k_pair_blocks");
     if (rc) return rc;
@@ -1398,7 +1418,7 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
     ProfScope ps(KID_PAIR_FINISH, st);
     hipLaunchKernelGGL(k_pair_finish, dim3(p->n_multi), dim3(64), 0, st, p->d_mb_blk, p->d_mb_part,
                          p->d_mb_cnt, p->d_blk_j, p->d_blk_k, spart, campart, p->d_cam_item_ptr, mu_u, p->m,
-                         fold_u, S, e);
+                         fold_u, S, e, static_cast<double*>(nullptr));
   }
       rc = check_launch("k_pair_finish");
       if (rc) return rc;
@@ -1417,13 +1437,14 @@ int launch_assemble_parts(const sfm_ba_plan* p, const int32_t* pt_map, const dou
   char* base = static_cast<char*>(ws);
   double* g = reinterpret_cast<double*>(base + p->ws_g);
   double* T = reinterpret_cast<double*>(base + p->ws_T);
+  double* qsq = reinterpret_cast<double*>(base + p->ws_q);
   double* spart = reinterpret_cast<double*>(base + p->ws_spart);
   if (p->n_groups > 0) {
     {
       ProfScope ps(KID_POINT, st);
       hipLaunchKernelGGL(k_point, dim3(p->n_groups), dim3(256), 0, st, pt_map, p->d_grp_pt, p->d_pt_ptr, p->d_perm,
                          p->d_tp_ptr, p->d_pair_entry, A, static_cast<const double*>(nullptr), xt, xp,
-                         static_cast<const double*>(nullptr), mu, 1, Vinv, eps_b, g, T);
+                         static_cast<const double*>(nullptr), mu, 1, Vinv, eps_b, g, qsq, T);
     }
     const int rc = check_launch("k_point");
     if (rc) return rc;
@@ -1433,8 +1454,9 @@ int launch_assemble_parts(const sfm_ba_plan* p, const int32_t* pt_map, const dou
       ProfScope ps(KID_PAIR_BLOCKS, st);
       hipLaunchKernelGGL(k_pair_blocks, dim3(p->n_pair_items), dim3(64), 0, st, p->n_pair_items, p->d_pit_blk, p->d_pit_beg,
                          p->d_pit_end, p->d_pit_part, p->d_blk_j, p->d_blk_k, p->d_entries, A, g,
-                         (unsigned)(p->ws_T - p->ws_g), 1, static_cast<const double*>(nullptr), p->d_cam_item_ptr, 0.0,
-                         p->m, static_cast<double*>(nullptr), static_cast<double*>(nullptr), spart);
+                         (unsigned)(p->ws_T - p->ws_g), (unsigned)(p->ws_q - p->ws_g), 1,
+                         static_cast<const double*>(nullptr), p->d_cam_item_ptr, 0.0, p->m, static_cast<double*>(nullptr),
+                         static_cast<double*>(nullptr), static_cast<double*>(nullptr), spart);
     }
     return check_launch("k_pair_blocks");
   }

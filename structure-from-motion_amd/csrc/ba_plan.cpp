@@ -37,6 +37,8 @@ void plan_set_workspace(sfm_ba_plan* p) {
   off = align256(off + p->n_obs * 2 * (int64_t)sizeof(double));
   p->ws_T = off;
   off = align256(off + (p->n_pair_slots + kPairPad) * 4 * (int64_t)sizeof(double));
+  p->ws_q = off;  // per observation: its squared residual and a zero (addressed like g, 16 bytes per observation)
+  off = align256(off + p->n_obs * 2 * (int64_t)sizeof(double));
   p->ws_campart = off;
   off = align256(off + (int64_t)std::max(p->n_items, 1) * SFM_BA_CAM_RED * (int64_t)sizeof(double));
   p->ws_spart = off;
@@ -176,8 +178,9 @@ int build_host(const int32_t* cam_idx, const int32_t* pt_idx, int64_t N, int32_t
       unit += is_long ? 1 : std::max(k, 1);
       tp_ptr[i] = (int32_t)pairs;
       pairs += (int64_t)k * (k + 1) / 2;
-      // 32-bit byte offsets into T, counted from the start of g that precedes it in the workspace
-      if (N * 16 + 256 + (pairs + kPairPad) * 32 >= (int64_t(1) << 32)) {
+      // 32-bit byte offsets into T and the per-observation array behind it, counted from the start of g
+      // that precedes them in the workspace
+      if (N * 32 + 512 + (pairs + kPairPad) * 32 >= (int64_t(1) << 32)) {
         delete p;
         return SFM_BA_ETOOBIG;
       }

@@ -641,8 +641,9 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
   SFMBA_TRY(read_stats());
   if (check && h[ST_NONUNIQUE]) return SFM_BA_ENONUNIQUE;
   if (N * 112 >= (int64_t(1) << 32)) return SFM_BA_ETOOBIG;  // 32-bit byte offsets into A
-  // 32-bit byte offsets into T, counted from the start of g that precedes it in the workspace
-  if (N * 16 + 256 + (pairs + kPairPad) * 32 >= (int64_t(1) << 32)) return SFM_BA_ETOOBIG;
+  // 32-bit byte offsets into T and the per-observation array behind it, counted from the start of g
+  // that precedes them in the workspace
+  if (N * 32 + 512 + (pairs + kPairPad) * 32 >= (int64_t(1) << 32)) return SFM_BA_ETOOBIG;
   p->n_pair_slots = pairs;
   p->n_entries = pairs;
   p->n_items = n_items;

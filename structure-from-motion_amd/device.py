@@ -269,6 +269,7 @@ class DeviceProblem:
         if P is not None:
             self.P.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(P, dtype=np.float64).reshape(-1, 12)[o])))
         self._blk_fresh = False
+        self._sys_fresh = False
 
     def _alloc(self):
         d, m, n, N = self.device, self.m, self.n, self.N
@@ -300,6 +301,8 @@ class DeviceProblem:
         self._packed_mu = None
         self._s_holds_foreign = False
         self._blk_fresh = False  # cam_blk holds the records of the current R, C, K
+        self._sys_fresh = False  # S, e, V_inv, eps_b and cost_buf are those of the current state (and of _sys_mu)
+        self._sys_mu = None
         if self.band_sharded:
             self.packed = torch.empty((int(self.lib.sfm_ba_band_packed_elements(n7)),), dtype=F64, device=d)
             self.compact = torch.empty((int(self.lib.sfm_ba_band_compact_elements(n7, self.half_bandwidth)),),
@@ -311,6 +314,7 @@ class DeviceProblem:
     # -- single stages ---------------------------------------------------------------------
     def camera_prepare(self):
         p = _lib.ptr
+        self._sys_fresh = False
         _lib.check(self.lib.sfm_ba_camera_prepare(p(self.R), p(self.C), p(self.K), self.k_stride, self.m,
                                                   p(self.cam_blk), p(self.flags), _stream()))
         self._blk_fresh = True
@@ -371,21 +375,34 @@ class DeviceProblem:
             _lib.check(self.lib.sfm_ba_lower_unpack(p(self.tri), n7, float(mu), p(self.S), _stream()))
             self.e.copy_(self.S[n7].view(self.m, 7))
 
-    def assemble_state(self, mu):
+    def assemble_state(self, mu, want_cost=False):  # noqa: D401
         """Jacobian blocks and Schur assembly in one pass (plans with a fused path): the rows of A of the
         near points are formed inside the assembly kernel from the camera records and the points and
-        never written; the far points go through the camera-pair kernels inside the same call."""
+        never written; the far points go through the camera-pair kernels inside the same call.
+        ``want_cost``: the per-camera sums of squared residuals of this state come out of the same
+        pass (``ssq``), and ``cost_buf`` receives the cost (src/bundle_adjustment.py:9-19)."""
         p = _lib.ptr
+        self._sys_fresh = False
         mu_u = self._prepare_system(mu, self.band_sharded)
+        if want_cost and self.sharded:
+            # the kernels write the sums of the cameras this rank observes; the others must not keep
+            # the totals of the previous all-reduce
+            self.ssq.zero_()
         _lib.check(self.lib.sfm_ba_schur_assemble_state(
             self.plan.handle, p(self.cam_blk), p(self.P), p(self.X), p(self.x_true), float(mu), float(mu_u),
-            p(self.S), p(self.e), p(self.V_inv), p(self.eps_b), p(self.workspace), _stream()))
+            p(self.S), p(self.e), p(self.V_inv), p(self.eps_b), p(self.ssq) if want_cost else None,
+            p(self.workspace), _stream()))
         self._exchange_system(mu, self.band_sharded)
+        if want_cost:
+            if self.sharded:
+                self._all_reduce(self.ssq)
+            _lib.check(self.lib.sfm_ba_cost_finish(p(self.ssq), self.m, p(self.cost_buf), _stream()))
 
     def back_substitute_state(self, update_points=False):
         """delta_b (and the point update) with the rows of A formed again from the state (the far
         points' rows are still in the workspace of the assembly)."""
         p = _lib.ptr
+        self._sys_fresh = self._sys_fresh and not update_points
         _lib.check(self.lib.sfm_ba_back_substitute_state(
             self.plan.handle, p(self.cam_blk), p(self.V_inv), p(self.eps_b), p(self.delta_a), p(self.delta_b),
             p(self.X), 1 if update_points else 0, float(self.X_STEP), p(self.workspace), _stream()))
@@ -395,6 +412,7 @@ class DeviceProblem:
         """``by_products=False`` skips U and eps_a (the solve needs only S and e): the library then
         folds the per-camera sums into the camera-pair kernel and makes one pass less over A."""
         p = _lib.ptr
+        self._sys_fresh = False
         reduce_packed = bool(reduce_packed) and self.band_sharded
         mu_u = self._prepare_system(mu, reduce_packed)
         _lib.check(self.lib.sfm_ba_schur_assemble(
@@ -408,6 +426,7 @@ class DeviceProblem:
 
     def solve(self):
         p = _lib.ptr
+        self._sys_fresh = False  # (the general factorisation works in place)
         if self._packed_mu is not None:
             _lib.check(self.lib.sfm_ba_solve_band_packed(p(self.packed), self.n7, self._packed_mu, p(self.delta_a),
                                                          p(self.chol_ws), p(self.info), _stream()))
@@ -417,6 +436,7 @@ class DeviceProblem:
 
     def back_substitute(self, weights=None, update_points=False, A=None, B=None):
         p = _lib.ptr
+        self._sys_fresh = self._sys_fresh and not update_points
         _lib.check(self.lib.sfm_ba_back_substitute(
             self.plan.handle, p(self.A if A is None else A), None if B is False else p(self.B if B is None else B),
             p(weights), p(self.V_inv), p(self.eps_b), p(self.delta_a), p(self.delta_b),
@@ -426,6 +446,7 @@ class DeviceProblem:
         """``prepare_next``: also leave the prepared camera records of the new state in ``cam_blk``
         (what ``camera_prepare`` would compute), so that the next iteration skips that launch."""
         p = _lib.ptr
+        self._sys_fresh = False
         if self.cam_pos is not None:
             # the camera the loop holds is the caller's camera 0, wherever the device order put it
             _lib.check(self.lib.sfm_ba_update_cameras_held(
@@ -471,11 +492,20 @@ class DeviceProblem:
         mu = self.MU if mu is None else mu
         if not self._blk_fresh:
             self.camera_prepare()
+            self._sys_fresh = False
         if self.from_state and self.plan.fused and mu > 0:
-            # plans with a fused path: the rows of A are formed inside the assembly and the back-substitution
-            self.assemble_state(mu)
+            # plans with a fused path: the rows of A are formed inside the assembly and the
+            # back-substitution, and the cost of a state is a by-product of its assembly: the
+            # iteration ends with the assembly of the state it produced - the system the next
+            # iteration solves, and the cost the loop looks at (src/bundle_adjustment.py:101)
+            if not (self._sys_fresh and self._sys_mu == mu):
+                self.assemble_state(mu, want_cost=True)
             self.solve()
             self.back_substitute_state(update_points=True)
+            self.update_cameras(prepare_next=True)
+            self.assemble_state(mu, want_cost=True)
+            self._sys_fresh, self._sys_mu = True, mu
+            return
         else:
             self.jacobian(want_B=False)
             self.assemble(mu, by_products=False, reduce_packed=True, B=False)
