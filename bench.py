@@ -349,10 +349,16 @@ def roofline_record(prof, groups, plan):
     # the fused kernel forms the rows of A itself: what it moves is a fraction of the stage's algorithmic
     # bytes and what bounds it is the fp64 pipe of the SIMDs, which the matrix and the vector instructions share
     kn = "k_fused_state"
-    slots = plan.fused_slots
-    tiles = 2 if slots <= 4 else (3 if slots <= 7 else 4)
-    mfma_flops = plan.n_steps * (tiles * (tiles + 1) // 2) * 6 * 2048.0
-    t = prof[kn][0] / prof[kn][1] * 1e-3
+    mfma_flops = 0.0
+    for c in plan.classes:
+        if not c["n_runs"]:
+            continue
+        slots = c["slots"]
+        tiles = 2 if slots <= 4 else (3 if slots <= 7 else (4 if slots <= 8 else 7))
+        k_steps = 6 if slots <= 8 else 3  # 8 points x 3 / 4 columns per matrix instruction; 4 points x 3 / 4
+        mfma_flops += c["n_steps"] * (tiles * (tiles + 1) // 2) * k_steps * 2048.0
+    launches_per_step = sum(1 for c in plan.classes if c["n_runs"])
+    t = prof[kn][0] / prof[kn][1] * launches_per_step * 1e-3  # (one launch per class of near points)
     tf = mfma_flops / t / 1e12
     return {
         "bound": "mfma", "kernel": name, "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -366,7 +372,8 @@ def roofline_record(prof, groups, plan):
         "frac_algorithmic_with_B": gr["priced_GBps_with_B"] / HBM_PEAK_GBS,
         "groups": groups,
         "note": "the dominant kernel forms the rows of A in registers and is bound by the fp64 pipe, not by HBM: achieved = "
-                "v_mfma_f64_16x16x4 flops it executes per launch (lower-triangle tiles x 6 per step of 8 points) / its "
+                "v_mfma_f64_16x16x4 flops it executes per iteration (lower-triangle tiles x 6 per step of 8 points; x 3 per "
+                "step of 4 points in windows of 16 cameras) / its "
                 "HIP-event time, against the dense fp64 peak; the same pipe also executes the kernel's vector fp64 "
                 "arithmetic, about as many cycles again.  traffic = HBM bytes per iteration of the stage from the "
                 "committed PMC passes (null: no pass for this workload).  achieved_algorithmic prices the bytes the two "
@@ -498,8 +505,8 @@ def main():
         pl = prob.plan
         if not (pl.fused and prob.from_state):
             return "fused point-major on materialised rows of A" if pl.fused else "camera-pair"
-        txt = f"fused point-major, rows of A formed in the kernel ({pl.n_near} near points in {pl.n_keys} windows of " \
-              f"{pl.fused_slots} cameras"
+        txt = "fused point-major, rows of A formed in the kernel (" + " + ".join(
+            f"{c['n_near']} near points in {c['n_keys']} windows of {c['slots']} cameras" for c in pl.classes if c["n_runs"])
         if pl.n_far:
             txt += f"; {pl.n_far} far points with {pl.n_far_obs} observations through the camera-pair kernels"
         return txt + ")"

@@ -87,12 +87,13 @@ void sfm_ba_plan_destroy(sfm_ba_plan* plan);
  * camera-sorted), 7-9 per-camera items (camera, begin, end), 10 cam_item_ptr, 11-12 block cameras
  * (j, k), 13 pair entries (two uint32 each), 14-17 pair items (block, begin, end, partial), 18-20
  * split blocks (block, first partial, partials); the fused assembly (all empty when the plan has no
- * runs): 21 first position of each run, 22 window of each run, 23 observation per (position, window
- * slot), 24 cameras of each window, 25 first run of each window, 26 first run of every range of positions
- * one wave walks, 27 point id at each position, 28 cameras of each run (for the kernels' loads), 29-30
- * per block the (window, slot, slot) entries the finishing kernel adds, 31-32 per block the far plan's
- * partial results, 33 far point ids, 34-37 per far observation: observation, camera, far point number,
- * point id.  *bytes receives the array's size; h_dst may be
+ * runs), per class of near points - fields 21-28 for class 0 (windows of up to 8 cameras), 121-128 for
+ * class 1 (windows of 16): 21 first position of each run, 22 window of each run, 23 observation per
+ * (position, window slot), 24 cameras of each window, 25 first run of each window, 26 first run of every
+ * range of positions one wave walks, 27 point id at each position, 28 cameras of each run (for the
+ * kernels' loads); 29-30 per block the (class, window, slot, slot) entries the finishing kernel adds,
+ * 31-32 per block the far plan's partial results, 33 far point ids, 34-37 per far observation:
+ * observation, camera, far point number, point id.  *bytes receives the array's size; h_dst may be
  * null to query it, otherwise `capacity` must be at least that size. */
 int sfm_ba_plan_read(const sfm_ba_plan* plan, int field, void* h_dst, int64_t capacity, int64_t* bytes);
 /* sizes: what[0]=n_cams, [1]=n_pts, [2]=n_obs, [3]=number of camera-pair blocks (j<=k) with a shared
@@ -104,24 +105,26 @@ int sfm_ba_plan_sizes(const sfm_ba_plan* plan, int64_t what[8]);
  * point).  `Indices.shared_point_indices` (src/sparse_ba.py:107-128) is where the reference finds
  * the same empty blocks, one pair at a time.  A sharded run takes the maximum over its ranks. */
 int32_t sfm_ba_plan_half_bandwidth(const sfm_ba_plan* plan);
-/* The fused assembly and its near / far split of the points.  A point seen by at most 4..8 cameras
- * (the width is chosen per plan from the observations' histogram) is "near": the plan sorts the near
- * points by the window of cameras they are seen from - consecutive cameras where the point's cameras
- * span no more than the width (what an incremental reconstruction produces: `Map.update_map`,
- * src/map.py:17-37, appends points as frames are registered; any order of the point ids), otherwise the
- * point's own camera set - and cuts that order into runs of one window each; sfm_ba_schur_assemble_state
- * (and sfm_ba_schur_assemble called without d_B, weights, d_U, d_eps_a and d_cam_red, with mu > 0) then
- * forms V^-1, eps_b and the near points' share of S and e in a single pass.  Points with more cameras,
- * and points whose window would hold fewer than 4 points, are "far": they form a plan of their own
- * (sfm_ba_plan_far, NULL when there is none) that goes through the camera-pair kernels, and the
- * finishing kernel adds both shares into S.  The reference's `Indices` / calc_S
- * (src/sparse_ba.py:58-97, 237-258) take any index order and any camera set; so does this.
- *   info[0] = 1 when that path will be taken, [1] = cameras per window (0: no fused path),
- *   [2] = near points, [3] = largest run length in points, [4] = runs,
- *   [5] = windows, [6] = steps (groups of up to 8 consecutive points of one run), [7] = ranges of
- *   positions (one wave each).  sfm_ba_plan_set_fused(plan, 0) turns the path off for this plan (tests
- *   compare the two paths); both give the same S and e to rounding. */
-int sfm_ba_plan_fused_info(const sfm_ba_plan* plan, int32_t info[8]);
+/* The fused assembly and its near / far split of the points.  A point seen by few cameras is "near":
+ * the plan sorts the near points by the window of cameras they are seen from - consecutive cameras where
+ * the point's cameras span no more than the window (what an incremental reconstruction produces:
+ * `Map.update_map`, src/map.py:17-37, appends points as frames are registered; any order of the point
+ * ids), otherwise the point's own camera set - and cuts that order into runs of one window each;
+ * sfm_ba_schur_assemble_state (and sfm_ba_schur_assemble called without d_B, weights, d_U, d_eps_a and
+ * d_cam_red, with mu > 0) then forms V^-1, eps_b and the near points' share of S and e in a single pass.
+ * Two classes of near points: class 0 with windows of 4..8 cameras (the width is chosen per plan from the
+ * observations' histogram), class 1 with windows of 16 cameras for the points class 0 leaves over (the
+ * longer tracks).  Points with more cameras, and points whose window would hold too few points (4 in
+ * class 0, 16 in class 1), are "far": they form a plan of their own (sfm_ba_plan_far, NULL when there is
+ * none) that goes through the camera-pair kernels, and the finishing kernel adds all shares into S.  The
+ * reference's `Indices` / calc_S (src/sparse_ba.py:58-97, 237-258) take any index order and any camera
+ * set; so does this.
+ *   info[8 c + 0] = 1 when class c will be used, [8 c + 1] = cameras per window (0: the class is empty),
+ *   [8 c + 2] = near points, [8 c + 3] = largest run length in points, [8 c + 4] = runs,
+ *   [8 c + 5] = windows, [8 c + 6] = steps (groups of up to 8 / 4 consecutive points of one run),
+ *   [8 c + 7] = ranges of positions (one wave each).  sfm_ba_plan_set_fused(plan, 0) turns the path off
+ *   for this plan (tests compare the two paths); both give the same S and e to rounding. */
+int sfm_ba_plan_fused_info(const sfm_ba_plan* plan, int32_t info[16]);
 int sfm_ba_plan_set_fused(sfm_ba_plan* plan, int enable);
 /* the plan over the far points' observations (owned by `plan`; NULL: every point is near, or the plan
  * has no fused path).  Its points are the far points renumbered 0 .. in ascending id. */

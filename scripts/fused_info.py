@@ -7,6 +7,6 @@ for w in ("c4_500x300k", "venice1800"):
     p = synthetic.make_workload(w, visibility="banded", seed=0)
     pl = Plan(p.cam_idx, p.pt_idx)
     rr = pl.read("rng_run"); rp = pl.read("run_pt0")
-    print(w, "fused", pl.fused, "slots", pl.fused_slots, "group", pl.fused_group, "pmax", pl.fused_pmax, "runs", pl.n_runs, "keys", pl.n_keys, "steps", pl.n_steps, "ranges", pl.n_ranges)
+    print(w, "fused", pl.fused, "classes", pl.classes, "far points", pl.n_far, "far observations", pl.n_far_obs)
     d = np.diff(rr); print(" runs per range: mean %.2f max %d" % (d.mean(), d.max()), "points per run: mean %.1f min %d" % (np.diff(rp).mean(), np.diff(rp).min()))
     print(" hist runs/range", np.bincount(d)[:12])

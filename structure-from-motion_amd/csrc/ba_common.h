@@ -19,22 +19,28 @@ constexpr int kPairPartStride = 64;  // doubles per partial result of a split bl
 
 // Fused point-major assembly.  The plan sorts the points it can handle this way ("near" points) by the
 // window of cameras they are seen from and walks them by position in that order:
-//   window  a list of up to `slots` (4..8) cameras.  A point whose cameras span at most `slots`
-//           consecutive ids uses a window of consecutive cameras (base = first camera rounded down to a
-//           multiple of slots - span + 1, so that points with nearby first cameras share it); a point
-//           with at most `slots` cameras that lie further apart uses its own camera set as the window
+//   window  a list of up to `slots` cameras.  A point whose cameras span at most `slots` consecutive ids
+//           uses a window of consecutive cameras (base = first camera rounded down to a multiple of
+//           slots - span + 1, so that points with nearby first cameras share it); a point with at most
+//           `slots` cameras that lie further apart uses its own camera set as the window
 //   run     consecutive positions of one window, cut at multiples of pmax; lane (point, slot) of a
-//           wave then owns one observation or none, 8 points per step
-// Points with more cameras than a window holds, and points whose window would hold fewer than
-// kFzMinWindowPoints points, are "far": they go through the camera-pair kernels of a second plan over
-// their observations, and the finishing kernel adds both kinds into S.
-constexpr int kFzLanesPerPoint = 8;  // lanes (= slot positions of the table) per point
+//           wave then owns one observation or none
+// There are two classes of near points: class 0 with windows of 4..8 cameras (8 lanes per point, 8 points
+// per step; the width is chosen per plan), and class 1 with windows of 16 cameras (16 lanes per point, 4
+// points per step) for the points class 0 leaves over - the longer tracks.  Points with more cameras
+// than that, and points whose window would hold too few points to be worth a partial result of its own,
+// are "far": they go through the camera-pair kernels of a second plan over their observations, and the
+// finishing kernel adds all of it into S.
+constexpr int kFzClasses = 2;
+constexpr int kFzMaxLanes = 16;      // lanes (= slot positions of the tables) per point: 8 (class 0) or 16 (class 1)
 constexpr int kFzMaxPmax = 1024;     // longest range of points one wave walks (and with it: runs per range)
 constexpr int kFzMaxRunsPerRange = 256;  // what the kernel that forms A itself keeps of a range's run boundaries
-constexpr int kFzMinWindowPoints = 4;    // a window with fewer points is not worth a partial result of its own
 constexpr int kFzSlotSums = 36;      // per-camera-slot sums behind a partial's tiles: 28 (upper triangle of
                                      // sum A^T A) + 7 (sum A^T g) + 1 (sum |eps|^2); 7 more per extra row
-// Cameras per window for a plan, from two histograms over the points with at most 8 cameras: obs_by_k[v]
+__host__ __device__ inline int fz_lanes(int slots) { return slots > 8 ? 16 : 8; }
+// a window with fewer points is not worth a partial result of its own (16 KiB .. 61 KiB)
+inline int fz_min_window_points(int cls) { return cls == 0 ? 4 : 16; }
+// Cameras per window of class 0, from two histograms over the points with at most 8 cameras: obs_by_k[v]
 // / obs_by_span[v] = observations of the points with v cameras / with a camera span of v (spans
 // beyond 8: not counted).  The smallest width that keeps 98 % of what a width of 8 would keep; measured
 // on the span when at least half of those observations belong to points that fit a window of
@@ -60,10 +66,13 @@ inline int fz_pmax_for(int32_t n_near) {
   const int pm = ((n_near + 2047) / 2048 + 7) & ~7;
   return pm < 32 ? 32 : (pm > kFzMaxPmax ? kFzMaxPmax : pm);
 }
-// the fused path is taken when the runs hold a step's worth of points on average (a run costs a partial
-// result of its own, about what two steps cost) and the near points are a fair share of all points
-inline bool fz_worthwhile(int32_t n, int32_t n_near, int32_t n_runs) {
-  return n_near > 0 && (int64_t)n_runs * 8 <= (int64_t)n_near + 1536 && (int64_t)n_near * 8 >= (int64_t)n;
+// A class is kept when its runs hold enough points on average (a run costs a partial result of its own:
+// about what two steps cost in class 0, and 61 KiB written and read in class 1) and its points are a
+// fair share of all points.
+inline bool fz_worthwhile(int cls, int32_t n, int32_t n_near, int32_t n_runs) {
+  if (n_near <= 0) return false;
+  if (cls == 0) return (int64_t)n_runs * 8 <= (int64_t)n_near + 1536 && (int64_t)n_near * 8 >= (int64_t)n;
+  return (int64_t)n_runs * 24 <= (int64_t)n_near + 1536 && (int64_t)n_near * 32 >= (int64_t)n;
 }
 // sort key of a near candidate: windows of consecutive cameras first, by base camera, then the
 // camera-set windows by a hash of the set (equal sets get equal keys; different sets with equal
@@ -76,10 +85,10 @@ __host__ __device__ inline uint32_t fz_hash_cams(const int32_t* cams, int k) {
   }
   return h;
 }
-// Window of a point with cameras cams[0..k) (ascending) in a plan with `slots` cameras per window and
-// m cameras: fills desc[0..8) (-1: no camera at that slot) and the sort key; false when the point does
-// not fit a window (k = 0 or k > slots).
-__host__ __device__ inline bool fz_point_window(const int32_t* cams, int k, int slots, int m, int32_t desc[8],
+// Window of a point with cameras cams[0..k) (ascending) in a class with `slots` cameras per window
+// (`lanes` table positions) and m cameras: fills desc[0..lanes) (-1: no camera at that slot) and the sort
+// key; false when the point does not fit a window (k = 0 or k > slots).
+__host__ __device__ inline bool fz_point_window(const int32_t* cams, int k, int slots, int lanes, int m, int32_t* desc,
                                                 uint64_t* key) {
   if (k < 1 || k > slots) return false;
   const int span = cams[k - 1] - cams[0] + 1;
@@ -88,32 +97,53 @@ __host__ __device__ inline bool fz_point_window(const int32_t* cams, int k, int 
     int base = cams[0] / g * g;
     const int last = m - slots > 0 ? m - slots : 0;  // windows do not reach past the last camera
     if (base > last) base = last;
-    for (int s = 0; s < 8; ++s) desc[s] = (s < slots && base + s < m) ? base + s : -1;
+    for (int s = 0; s < lanes; ++s) desc[s] = (s < slots && base + s < m) ? base + s : -1;
     *key = (uint64_t)(uint32_t)base;
   } else {
-    for (int s = 0; s < 8; ++s) desc[s] = s < k ? cams[s] : -1;
+    for (int s = 0; s < lanes; ++s) desc[s] = s < k ? cams[s] : -1;
     *key = (uint64_t(1) << 32) | fz_hash_cams(cams, k);
   }
   return true;
 }
 // slot of camera c in the window desc (the camera is there)
-__host__ __device__ inline int fz_slot_of(const int32_t desc[8], int32_t c) {
-  for (int s = 0; s < 8; ++s)
+__host__ __device__ inline int fz_slot_of(const int32_t* desc, int lanes, int32_t c) {
+  for (int s = 0; s < lanes; ++s)
     if (desc[s] == c) return s;
   return -1;
 }
 // the 7 * slots rows of a window: 16 per row tile of the matrix cores, the rest ("extra rows") summed by the lanes
-__host__ __device__ inline int fz_row_tiles(int slots) { return slots <= 4 ? 2 : (slots <= 7 ? 3 : 4); }
+__host__ __device__ inline int fz_row_tiles(int slots) { return slots <= 4 ? 2 : (slots <= 7 ? 3 : (slots <= 8 ? 4 : 7)); }
 __host__ __device__ inline int fz_extra_rows(int slots) { return slots == 7 ? 1 : 0; }
 // doubles of one partial result: lower-triangle tiles (16 x 16), then the per-slot sums as
-// [value][slot] (value i of slot s at 8 i + s: 28 of U, 7 of e, the squared residuals, 7 per extra
+// [value][slot] (value i of slot s at lanes i + s: 28 of U, 7 of e, the squared residuals, 7 per extra
 // row), rounded up to whole 256-byte units
-__host__ __device__ constexpr int64_t fz_part_stride_c(int tiles, int extra) {
-  return (int64_t)(tiles * (tiles + 1) / 2) * 256 + (((kFzSlotSums + 7 * extra) * 8 + 31) & ~31);
+__host__ __device__ constexpr int64_t fz_part_stride_c(int tiles, int extra, int lanes) {
+  return (int64_t)(tiles * (tiles + 1) / 2) * 256 + (((kFzSlotSums + 7 * extra) * lanes + 31) & ~31);
 }
 __host__ __device__ inline int64_t fz_part_stride(int slots) {
-  return fz_part_stride_c(fz_row_tiles(slots), fz_extra_rows(slots));
+  return fz_part_stride_c(fz_row_tiles(slots), fz_extra_rows(slots), fz_lanes(slots));
 }
+// entry of the finishing kernel: class, window, slot of camera j, slot of camera k
+__host__ __device__ inline int32_t fz_fb_pack(int cls, int key, int sj, int sk) { return (cls << 30) | (key << 8) | (sj << 4) | sk; }
+
+// one class of near points: its tables on the device
+struct FzClass {
+  int32_t slots = 0;  // cameras per window (0: the class is empty)
+  int32_t lanes = 8;  // table positions per point
+  int32_t pmax = 0, n_near = 0, n_runs = 0, n_keys = 0, n_ranges = 0, n_steps = 0;
+  int32_t max_range_runs = 0;     // most runs inside one range of pmax positions
+  int32_t* d_pt = nullptr;        // [n_near] point id at every position
+  int32_t* d_slot_obs = nullptr;  // [n_near][lanes] observation (caller order) of the point at that position by the
+                                  // camera at that slot of its window, or -1
+  int32_t* d_run_pt0 = nullptr;   // [n_runs+1] first position of each run
+  int32_t* d_run_key = nullptr;   // [n_runs] window of the run
+  int32_t* d_run_cam = nullptr;   // [n_runs][lanes] cameras of the run's window, for the kernels' loads: a slot
+                                  // without a camera repeats the window's first camera
+  int32_t* d_rng_run = nullptr;   // [n_ranges+1] first run of every range of pmax positions (one wave per range)
+  int32_t* d_key_cam = nullptr;   // [n_keys][lanes] camera at every slot of the window, -1: none
+  int32_t* d_key_run = nullptr;   // [n_keys+1] first run of every window (the runs of a window are consecutive)
+  int64_t ws_part = 0, ws_key = 0;  // workspace: one partial result per run, one per window
+};
 
 // One (observation, observation) pair of a camera-pair block, as byte offsets (the kernel that walks
 // these adds a piece offset and issues the fetch; N * 112 < 2^32 is checked when the plan is built)
@@ -164,24 +194,13 @@ struct sfm_ba_plan {
   int32_t* d_mb_blk = nullptr;
   int32_t* d_mb_part = nullptr;   // first partial
   int32_t* d_mb_cnt = nullptr;    // number of partials
-  // fused point-major assembly over the near points (fz_slots = 0: the plan has none)
-  int32_t fz_slots = 0, fz_pmax = 0, fz_enabled = 1;
-  int32_t n_near = 0;             // near points = positions of the tables below
-  int32_t n_runs = 0, n_keys = 0, n_ranges = 0, n_steps = 0;
-  int32_t fz_max_range_runs = 0;  // most runs inside one range of fz_pmax positions
-  int32_t* d_fz_pt = nullptr;     // [n_near] point id at every position
-  int32_t* d_slot_obs = nullptr;  // [n_near][8] observation (caller order) of the point at that position by the
-                                  // camera at that slot of its window, or -1
-  int32_t* d_run_pt0 = nullptr;   // [n_runs+1] first position of each run
-  int32_t* d_run_key = nullptr;   // [n_runs] window of the run
-  int32_t* d_run_cam = nullptr;   // [n_runs][8] cameras of the run's window, for the kernels' loads: a slot
-                                  // without a camera repeats the window's first camera
-  int32_t* d_rng_run = nullptr;   // [n_ranges+1] first run of every range of fz_pmax positions (one wave per range)
-  int32_t* d_key_cam = nullptr;   // [n_keys][8] camera at every slot of the window, -1: none
-  int32_t* d_key_run = nullptr;   // [n_keys+1] first run of every window (the runs of a window are consecutive)
+  // fused point-major assembly over the near points (n_runs = 0: the plan has none)
+  sfmba::FzClass fz[sfmba::kFzClasses];
+  int32_t fz_enabled = 1;
+  int32_t n_runs = 0;  // runs of both classes
   // per camera-pair block (the plan's blocks, j <= k): where the finishing kernel finds its sums
   int32_t* d_fb_ptr = nullptr;    // [n_blocks+1] entries of the block in d_fb_ent
-  int32_t* d_fb_ent = nullptr;    // [n_fb] window << 6 | slot of camera j << 3 | slot of camera k
+  int32_t* d_fb_ent = nullptr;    // [n_fb] fz_fb_pack(class, window, slot of camera j, slot of camera k)
   int32_t* d_fb_far_part = nullptr;  // [n_blocks] first partial result of the block in the far plan's workspace
   int32_t* d_fb_far_cnt = nullptr;   // [n_blocks] number of those partials (0: the far points do not touch the block)
   int32_t n_fb = 0;
@@ -198,7 +217,7 @@ struct sfm_ba_plan {
   int32_t force_parts = 0;        // this plan is the far plan of another: every block writes partial results
   int64_t device_bytes = 0;
   // workspace section offsets (bytes)
-  int64_t ws_g = 0, ws_T = 0, ws_q = 0, ws_campart = 0, ws_spart = 0, ws_fpart = 0, ws_fkey = 0, ws_fzero = 0, ws_far_A = 0,
+  int64_t ws_g = 0, ws_T = 0, ws_q = 0, ws_campart = 0, ws_spart = 0, ws_fzero = 0, ws_far_A = 0,
           ws_far_xt = 0, ws_far_xp = 0, ws_far = 0, ws_total = 0;
 };
 

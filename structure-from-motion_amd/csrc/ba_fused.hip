@@ -83,6 +83,14 @@ __device__ __forceinline__ double sum8(double v) {
   return v;
 }
 
+// sum over the LPP (8 or 16) lanes of a point, in every lane of the group
+template <int LPP>
+__device__ __forceinline__ double sum_point(double v) {
+  v = sum8(v);
+  if (LPP == 16) v += dpp64<0x140>(v);  // row_mirror: the other half of the row of 16 (all eight lanes of a half agree)
+  return v;
+}
+
 // value of lane SX (0..7) of this lane's group of 8, in every lane of the group
 template <int SX>
 __device__ __forceinline__ double bcast8(double v, int s) {
@@ -116,7 +124,8 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 // what lanes of k_fused_runs without an observation read as their operands: zeros, never written
 __device__ __align__(256) const double g_fz_zero_row[32] = {0.0};
 
-template <int W, int T, int E, int WPS>  // WPS: waves per SIMD the register allocation leaves room for
+template <int W, int T, int E, int WPS, int LPP>  // WPS: waves per SIMD the register allocation leaves room for;
+                                                 // LPP: lanes (= camera slots of the tables) per point
 __global__ __launch_bounds__(64, WPS) void k_fused_runs(
     const int32_t* __restrict__ rng_run, const int32_t* __restrict__ run_pt0,
     const int32_t* __restrict__ slot_obs, const int32_t* __restrict__ fz_pt, const double* __restrict__ A,
@@ -126,15 +135,19 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
   static_assert(16 * T + E >= 7 * W && 16 * T <= 7 * W + 15, "tiles and extra rows must cover the window");
   static_assert(E == 0 || (16 * T) / 7 == (16 * T + E - 1) / 7, "the extra rows belong to one camera slot");
   static_assert(E == 0 || (16 * T) / 7 == 4 || (16 * T) / 7 == 6, "extra rows are wired for slots 4 and 6");
-  constexpr int KS = 64;  // doubles per K column of the panel: 8 per camera slot (7 rows + a zero)
+  static_assert(LPP == 8 || LPP == 16, "8 or 16 lanes per point");
+  static_assert(E == 0 || LPP == 8, "extra rows are wired for 8 lanes per point");
+  constexpr int PPS = 64 / LPP;   // points per step
+  constexpr int KS = 8 * LPP;     // doubles per K column of the panel: 8 per camera slot (7 rows + a zero)
+  constexpr int NK = 3 * PPS / 4; // K steps of 4 columns per step
   constexpr int NT = T * (T + 1) / 2;
-  constexpr int64_t STRIDE = fz_part_stride_c(T, E);
-  __shared__ __attribute__((aligned(16))) double Zp[24 * KS];  // [K column = 3 point + q][8 slot + r]
+  constexpr int64_t STRIDE = fz_part_stride_c(T, E, LPP);
+  __shared__ __attribute__((aligned(16))) double Zp[3 * PPS * KS];  // [K column = 3 point + q][8 slot + r]
   __shared__ int bnd[kFzMaxPmax + 1];  // first point of every run of this wave's range, and the range's end
 #define FZ_RESIDUAL_IN_ROWS false
   const int lane = threadIdx.x;
   const double* zero_row = g_fz_zero_row;
-  const int p = lane >> 3, s = lane & 7;
+  const int p = lane / LPP, s = lane % LPP;
   const int li = lane & 15, lk = lane >> 4;
   // panel offset of dense row 16 t + li for the operand reads (rows past the window: a zero entry)
   int roff[T];
@@ -155,8 +168,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
   // (a 32-bit index: the address is then the kernel argument plus a lane offset; as a 64-bit per-lane
   // pointer it is kept in registers across the steps, spilled, and every reload of a spill waits for
   // all loads in flight - the next step's operands)
-#define FZ_FETCH_POS(first, lim) \
-  (((first) + p) < (lim) ? slot_obs[(unsigned)(kFzLanesPerPoint * ((first) + p) + s)] : -1)
+#define FZ_FETCH_POS(first, lim) (((first) + p) < (lim) ? slot_obs[(unsigned)(LPP * ((first) + p) + s)] : -1)
   // row of A (a_(0..13)), x_true (a_(14..15)) and x_pred (a_(16..17)) of observation `pos`; a lane
   // without an observation reads the row of zeros the launcher keeps in the workspace (selecting the
   // address keeps the loads unconditional, so that they land in the registers of av[] themselves)
@@ -173,7 +185,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
   // step after the one that starts at `first` in run `r`: 8 points on, or the start of the next run
 #define FZ_ADVANCE(first, r)                                                    \
   do {                                                                          \
-    (first) += 8;                                                               \
+    (first) += PPS;                                                             \
     if ((first) >= __builtin_amdgcn_readfirstlane(bnd[(r) + 1])) {              \
       (r) += 1;                                                                 \
       (first) = __builtin_amdgcn_readfirstlane(bnd[(r)]);                       \
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
   // point id of the lane's point in the step that starts at position `first`
 #define FZ_FETCH_PID(first) fz_pt[(unsigned)(((first) + p) < n_pts ? (first) + p : n_pts - 1)]
   const int pt_first = f0 + p < n_pts ? f0 + p : n_pts - 1;
-  const int pos_raw = slot_obs[(unsigned)(kFzLanesPerPoint * pt_first + s)];
+  const int pos_raw = slot_obs[(unsigned)(LPP * pt_first + s)];
   int pid = fz_pt[(unsigned)pt_first];
   for (int i = lane; i <= nr; i += 64) bnd[i] = run_pt0[run0 + i];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_runs(
   // code of that part which the compiler moved into the steps (it does so when the end of a run is
   // a branch inside one flat loop) makes every step wait for its matrix instructions
   const int run = run0 + r0;
-  int nsteps = (FZ_LIM(r0) - f0 + 7) >> 3;
+  int nsteps = (FZ_LIM(r0) - f0 + PPS - 1) / PPS;
   asm volatile("" : "+s"(nsteps));
   int step = 0;
   do {  // (at least one step: the loop's exit then has a block of its own for the copies the write-out needs)
@@ -382,7 +394,7 @@ __device__ __forceinline__ void fz_rows_from_state(RecT r2, PmT p2, double x0, d
 // matrices of the 8 cameras of the current run's window sit in LDS (4 352 bytes, reloaded when the
 // next step belongs to another run); the point and x_true of the next step are fetched at the top of
 // a step and turned into its operands behind the panel stores, where k_fused_runs issues its gathers.
-template <int W, int T, int E, int WPS>
+template <int W, int T, int E, int WPS, int LPP>
 __global__ __launch_bounds__(64, WPS) void k_fused_state(
     const int32_t* __restrict__ rng_run, const int32_t* __restrict__ run_pt0, const int32_t* __restrict__ run_cam,
     const int32_t* __restrict__ slot_obs, const int32_t* __restrict__ fz_pt, const double* __restrict__ blk,
@@ -390,17 +402,24 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
     const double* __restrict__ X, const double* __restrict__ xt, double mu, double* __restrict__ Vinv,
     double* __restrict__ eps_b, double* __restrict__ part, int pmax, int n_pts, int m) {
   static_assert(16 * T + E >= 7 * W && 16 * T <= 7 * W + 15, "tiles and extra rows must cover the window");
-  constexpr int KS = 64;
+  static_assert(LPP == 8 || LPP == 16, "8 or 16 lanes per point");
+  static_assert(E == 0 || LPP == 8, "extra rows are wired for 8 lanes per point");
+  constexpr int PPS = 64 / LPP;
+  constexpr int KS = 8 * LPP;
+  constexpr int NK = 3 * PPS / 4;
   constexpr int NT = T * (T + 1) / 2;
-  constexpr int64_t STRIDE = fz_part_stride_c(T, E);
+  constexpr int64_t STRIDE = fz_part_stride_c(T, E, LPP);
   constexpr int REC = SFM_BA_CAM_BLK;
-  constexpr int RS = REC + 2;  // record stride in LDS: 58 doubles = 116 dwords, the 8 cameras' 16-byte reads hit 8 different bank groups
-  __shared__ __attribute__((aligned(16))) double Zp[24 * KS];
-  __shared__ __attribute__((aligned(16))) double sRec[8 * (RS + 12)];  // 8 records, then 8 projection matrices
+  constexpr int RS = REC + 2;  // record stride in LDS: 58 doubles = 116 dwords, the cameras' 16-byte reads hit different bank groups
+  // the lane keeps its camera's record in registers for the whole run (one wave per SIMD, 8 lanes per point;
+  // with 16 lanes per point the accumulator tiles leave no room for it)
+  constexpr bool REGS = WPS == 1 && LPP == 8;
+  __shared__ __attribute__((aligned(16))) double Zp[3 * PPS * KS];
+  __shared__ __attribute__((aligned(16))) double sRec[LPP * (RS + 12)];  // LPP records, then LPP projection matrices
   __shared__ int bnd[kFzMaxRunsPerRange + 1];
 #define FZ_RESIDUAL_IN_ROWS true
   const int lane = threadIdx.x;
-  const int p = lane >> 3, s = lane & 7;
+  const int p = lane / LPP, s = lane % LPP;
   const int li = lane & 15, lk = lane >> 4;
   int roff[T];
 #pragma unroll
@@ -412,11 +431,10 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
   const int run0 = rng_run[blockIdx.x];
   const int nr = rng_run[blockIdx.x + 1] - run0;
   int f0 = blockIdx.x * pmax, r0 = 0;
-#define FZ_FETCH_POS(first, lim) \
-  (((first) + p) < (lim) ? slot_obs[(unsigned)(kFzLanesPerPoint * ((first) + p) + s)] : -1)
+#define FZ_FETCH_POS(first, lim) (((first) + p) < (lim) ? slot_obs[(unsigned)(LPP * ((first) + p) + s)] : -1)
 #define FZ_ADVANCE(first, r)                                                    \
   do {                                                                          \
-    (first) += 8;                                                               \
+    (first) += PPS;                                                             \
     if ((first) >= __builtin_amdgcn_readfirstlane(bnd[(r) + 1])) {              \
       (r) += 1;                                                                 \
       (first) = __builtin_amdgcn_readfirstlane(bnd[(r)]);                       \
@@ -427,19 +445,22 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
   // lists a camera for every slot: slots without one repeat the first, they hold no observation)
 #define FZ_LOAD_WINDOW(rr)                                                                         \
   do {                                                                                             \
-    const int32_t* wc_ = run_cam + 8 * (int64_t)(run0 + (rr));                                     \
+    const int32_t* wc_ = run_cam + LPP * (int64_t)(run0 + (rr));                                   \
     const double2* src_ = reinterpret_cast<const double2*>(blk);                                   \
     double2* dst_ = reinterpret_cast<double2*>(sRec);                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < (8 * REC / 2 + 63) / 64; ++i_) {                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < (LPP * REC / 2 + 63) / 64; ++i_) {                     \
       const int e_ = lane + 64 * i_;                                                               \
-      if (e_ < 8 * REC / 2) {                                                                      \
+      if (e_ < LPP * REC / 2) {                                                                    \
         const int c_ = wc_[e_ / (REC / 2)];                                                        \
         dst_[(e_ / (REC / 2)) * (RS / 2) + e_ % (REC / 2)] = src_[(int64_t)c_ * (REC / 2) + e_ % (REC / 2)]; \
       }                                                                                            \
     }                                                                                              \
-    if (lane < 48) {                                                                               \
-      const int c_ = wc_[lane / 6];                                                                \
-      dst_[8 * RS / 2 + lane] = reinterpret_cast<const double2*>(P)[(int64_t)c_ * 6 + lane % 6];   \
+    _Pragma("unroll") for (int i_ = 0; i_ < (6 * LPP + 63) / 64; ++i_) {                           \
+      const int e_ = lane + 64 * i_;                                                               \
+      if (e_ < 6 * LPP) {                                                                          \
+        const int c_ = wc_[e_ / 6];                                                                \
+        dst_[LPP * RS / 2 + e_] = reinterpret_cast<const double2*>(P)[(int64_t)c_ * 6 + e_ % 6];   \
+      }                                                                                            \
     }                                                                                              \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                         \
     __builtin_amdgcn_wave_barrier();                                                               \
@@ -459,26 +480,26 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
   // With one wave per SIMD (512 registers) the lane keeps its camera's record and projection matrix
   // in registers for the whole run: they change with the window only.  With two waves per SIMD they
   // are read from LDS at every step.
-  double2 rreg[WPS == 1 ? 28 : 1], preg[WPS == 1 ? 6 : 1];
+  double2 rreg[REGS ? 28 : 1], preg[REGS ? 6 : 1];
 #define FZ_RECORD_TO_REGS()                                                                                 \
   do {                                                                                                      \
-    if (WPS == 1) {                                                                                         \
+    if (REGS) {                                                                                             \
       const double2* r_ = reinterpret_cast<const double2*>(sRec + RS * s);                                  \
-      const double2* q_ = reinterpret_cast<const double2*>(sRec + 8 * RS + 12 * s);                         \
-      _Pragma("unroll") for (int i_ = 0; i_ < 28; ++i_) rreg[WPS == 1 ? i_ : 0] = r_[i_];                   \
-      _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) preg[WPS == 1 ? i_ : 0] = q_[i_];                    \
+      const double2* q_ = reinterpret_cast<const double2*>(sRec + LPP * RS + 12 * s);                       \
+      _Pragma("unroll") for (int i_ = 0; i_ < 28; ++i_) rreg[REGS ? i_ : 0] = r_[i_];                       \
+      _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) preg[REGS ? i_ : 0] = q_[i_];                        \
     }                                                                                                       \
   } while (0)
 #define FZ_ROWS(X0, X1, X2, XT, HAS)                                                                        \
   do {                                                                                                      \
-    if (WPS == 1)                                                                                           \
+    if (REGS)                                                                                               \
       fz_rows_from_state<true, false>(rreg, preg, X0, X1, X2, XT, HAS, av);                                 \
     else                                                                                                    \
       fz_rows_from_state<true, true>(reinterpret_cast<const double2*>(sRec + RS * s),                       \
-                                     reinterpret_cast<const double2*>(sRec + 8 * RS + 12 * s), X0, X1, X2, XT, HAS, av); \
+                                     reinterpret_cast<const double2*>(sRec + LPP * RS + 12 * s), X0, X1, X2, XT, HAS, av); \
   } while (0)
   const int pt_first = f0 + p < n_pts ? f0 + p : n_pts - 1;
-  const int pos_raw = slot_obs[(unsigned)(kFzLanesPerPoint * pt_first + s)];
+  const int pos_raw = slot_obs[(unsigned)(LPP * pt_first + s)];
   int pid = fz_pt[(unsigned)pt_first];
   for (int i = lane; i <= nr; i += 64) bnd[i] = run_pt0[run0 + i];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -519,7 +540,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
   FZ_STAMP(0);
   while (r0 < nr) {  // runs of the range
   const int run = run0 + r0;
-  int nsteps = (FZ_LIM(r0) - f0 + 7) >> 3;
+  int nsteps = (FZ_LIM(r0) - f0 + PPS - 1) / PPS;
   asm volatile("" : "+s"(nsteps));
   int step = 0;
   do {
@@ -576,31 +597,37 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
 // Back-substitution straight from the state (src/sparse_ba.py:279-290 and the point update of
 // src/bundle_adjustment.py:100): delta_b_i = V_i^-1 (eps_b_i - sum_s B_s^T A_s delta_a[cam_s]) with the
 // rows of A formed in the kernel as in k_fused_state (B = minus the camera-centre columns of A).
-// One wave per range of positions, a step of 8 points at a time; the window's camera records and its 56
-// entries of delta_a sit in LDS.  X is read before it is updated: a point's rows depend on no other point.
+// One wave per range of positions, a step of 64 / LPP points at a time; the window's camera records and
+// its entries of delta_a sit in LDS.  X is read before it is updated: a point's rows depend on no other point.
+template <int LPP>
 __global__ __launch_bounds__(64) void k_back_substitute_state(
     const int32_t* __restrict__ rng_run, const int32_t* __restrict__ run_pt0, const int32_t* __restrict__ run_cam,
     const int32_t* __restrict__ slot_obs, const int32_t* __restrict__ fz_pt, const double* __restrict__ blk,
     const double* __restrict__ Vinv, const double* __restrict__ eps_b, const double* __restrict__ da,
     double* __restrict__ db, double* __restrict__ X, int update, double x_step) {
   constexpr int REC = SFM_BA_CAM_BLK;
-  __shared__ __attribute__((aligned(16))) double sRec[8 * REC];
-  __shared__ double sDa[56];
+  constexpr int PPS = 64 / LPP;
+  __shared__ __attribute__((aligned(16))) double sRec[LPP * REC];
+  __shared__ double sDa[7 * LPP];
   const int lane = threadIdx.x;
-  const int p = lane >> 3, s = lane & 7;
+  const int p = lane / LPP, s = lane % LPP;
   const int run_first = rng_run[blockIdx.x], run_last = rng_run[blockIdx.x + 1];
   for (int run = run_first; run < run_last; ++run) {
     const int beg = __builtin_amdgcn_readfirstlane(run_pt0[run]), end = __builtin_amdgcn_readfirstlane(run_pt0[run + 1]);
     {
-      const int32_t* wc = run_cam + 8 * (int64_t)run;
+      const int32_t* wc = run_cam + LPP * (int64_t)run;
       const double2* src = reinterpret_cast<const double2*>(blk);
       double2* dst = reinterpret_cast<double2*>(sRec);
 #pragma unroll
-      for (int i = 0; i < (8 * REC / 2 + 63) / 64; ++i) {
+      for (int i = 0; i < (LPP * REC / 2 + 63) / 64; ++i) {
         const int e = lane + 64 * i;
-        if (e < 8 * REC / 2) dst[e] = src[(int64_t)wc[e / (REC / 2)] * (REC / 2) + e % (REC / 2)];
+        if (e < LPP * REC / 2) dst[e] = src[(int64_t)wc[e / (REC / 2)] * (REC / 2) + e % (REC / 2)];
       }
-      if (lane < 56) sDa[lane] = da[7 * (int64_t)wc[lane / 7] + lane % 7];
+#pragma unroll
+      for (int i = 0; i < (7 * LPP + 63) / 64; ++i) {
+        const int e = lane + 64 * i;
+        if (e < 7 * LPP) sDa[e] = da[7 * (int64_t)wc[e / 7] + e % 7];
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -613,24 +640,24 @@ __global__ __launch_bounds__(64) void k_back_substitute_state(
 #define FZ_BS_FETCH(first, pid_)                                                          \
   do {                                                                                    \
     const int ptn_ = (first) + p < end ? (first) + p : end - 1;                           \
-    pos_n = (first) + p < end ? slot_obs[(unsigned)(kFzLanesPerPoint * ptn_ + s)] : -1;   \
+    pos_n = (first) + p < end ? slot_obs[(unsigned)(LPP * ptn_ + s)] : -1;                \
     const double* xq_ = X + 3 * (int64_t)(pid_);                                          \
     xn0 = xq_[0];                                                                         \
     xn1 = xq_[1];                                                                         \
     xn2 = xq_[2];                                                                         \
   } while (0)
     pid_n = FZ_BS_PID(beg);
-    pid_n2 = FZ_BS_PID(beg + 8);
+    pid_n2 = FZ_BS_PID(beg + PPS);
     FZ_BS_FETCH(beg, pid_n);
-    for (int f = beg; f < end; f += 8) {
+    for (int f = beg; f < end; f += PPS) {
       const bool live = f + p < end;
       const int pos = pos_n;
       const int pid = pid_n;
       const double x0 = xn0, x1 = xn1, x2 = xn2;
       pid_n = pid_n2;
-      if (f + 8 < end) {
-        FZ_BS_FETCH(f + 8, pid_n);
-        pid_n2 = FZ_BS_PID(f + 16);
+      if (f + PPS < end) {
+        FZ_BS_FETCH(f + PPS, pid_n);
+        pid_n2 = FZ_BS_PID(f + 2 * PPS);
       }
       double vv[9], eb[3];
       if (s == 0 && live) {
@@ -651,9 +678,9 @@ __global__ __launch_bounds__(64) void k_back_substitute_state(
         h0 += a_(q) * dj[q];
         h1 += a_(7 + q) * dj[q];
       }
-      const double c0 = sum8(-a_(4) * h0 - a_(11) * h1);
-      const double c1 = sum8(-a_(5) * h0 - a_(12) * h1);
-      const double c2 = sum8(-a_(6) * h0 - a_(13) * h1);
+      const double c0 = sum_point<LPP>(-a_(4) * h0 - a_(11) * h1);
+      const double c1 = sum_point<LPP>(-a_(5) * h0 - a_(12) * h1);
+      const double c2 = sum_point<LPP>(-a_(6) * h0 - a_(13) * h1);
 #undef a_
       if (s == 0 && live) {
         const double r0 = eb[0] - c0, r1 = eb[1] - c1, r2 = eb[2] - c2;
@@ -703,17 +730,15 @@ __global__ __launch_bounds__(256) void k_fused_reduce(const int32_t* __restrict_
 __global__ __launch_bounds__(64) void k_fused_finish(const int32_t* __restrict__ blk_j, const int32_t* __restrict__ blk_k,
                                                      const int32_t* __restrict__ fb_ptr, const int32_t* __restrict__ fb_ent,
                                                      const int32_t* __restrict__ fb_far_part,
-                                                     const int32_t* __restrict__ fb_far_cnt, int slots,
-                                                     const double* __restrict__ kpart, const double* __restrict__ far_part,
-                                                     double mu_u, int m, double* __restrict__ S, double* __restrict__ e_out,
+                                                     const int32_t* __restrict__ fb_far_cnt, int slots0, int slots1,
+                                                     const double* __restrict__ kpart0, const double* __restrict__ kpart1,
+                                                     const double* __restrict__ far_part, double mu_u, int m,
+                                                     double* __restrict__ S, double* __restrict__ e_out,
                                                      double* __restrict__ ssq_out) {
   // threads 0..48: the 7 x 7 block; 49..55: e_j, 56: the camera's sum of squared residuals (diagonal blocks)
   const int t = threadIdx.x;
   const int j = blk_j[blockIdx.x], k = blk_k[blockIdx.x];
   if (t >= 57 || (t >= 49 && j != k)) return;
-  const int T = fz_row_tiles(slots), E = fz_extra_rows(slots);
-  const int nt = T * (T + 1) / 2;
-  const int64_t stride = fz_part_stride_c(T, E);
   const int r = t / 7, c = t - 7 * r;
   const int ulo = r < c ? r : c, uhi = r < c ? c : r;
   const int uidx = ulo * 7 - ulo * (ulo - 1) / 2 + (uhi - ulo);
@@ -721,8 +746,11 @@ __global__ __launch_bounds__(64) void k_fused_finish(const int32_t* __restrict__
   const int e_end = fb_ptr[blockIdx.x + 1];
   for (int en = fb_ptr[blockIdx.x]; en < e_end; ++en) {
     const int ent = fb_ent[en];
-    const int sj = (ent >> 3) & 7, sk = ent & 7;
-    const double* pb = kpart + (int64_t)(ent >> 6) * stride;
+    const int cls = (ent >> 30) & 1, sj = (ent >> 4) & 15, sk = ent & 15;
+    const int slots = cls ? slots1 : slots0;
+    const int T = fz_row_tiles(slots), lanes = fz_lanes(slots);
+    const int nt = T * (T + 1) / 2;
+    const double* pb = (cls ? kpart1 : kpart0) + (int64_t)((ent >> 8) & 0x3FFFFF) * fz_part_stride(slots);
     if (t < 49) {
       // (Y_j W_k^T)[r][c] = D[7 sk + c][7 sj + r]; D is symmetric and its lower triangle is stored
       // (a diagonal block takes both of its triangles from the lower one)
@@ -737,12 +765,12 @@ __global__ __launch_bounds__(64) void k_fused_finish(const int32_t* __restrict__
         const int ti = row >> 4, tj = col >> 4;
         v = pb[(ti * (ti + 1) / 2 + tj) * 256 + (row & 15) * 16 + (col & 15)];
       } else {
-        v = pb[nt * 256 + (kFzSlotSums + 7 * (row - 16 * T) + col % 7) * 8 + col / 7];
+        v = pb[nt * 256 + (kFzSlotSums + 7 * (row - 16 * T) + col % 7) * lanes + col / 7];
       }
-      if (j == k) v = pb[nt * 256 + uidx * 8 + sj] - v;
+      if (j == k) v = pb[nt * 256 + uidx * lanes + sj] - v;
       sum += v;
     } else {
-      sum += pb[nt * 256 + (28 + (t - 49)) * 8 + sj];  // (t = 56: value 35, the squared residuals)
+      sum += pb[nt * 256 + (28 + (t - 49)) * lanes + sj];  // (t = 56: value 35, the squared residuals)
     }
   }
   // the far points' share: sum A_j^T T A_k over their entries of the pair, which on the diagonal holds
@@ -827,16 +855,16 @@ static void fz_print_stamps() {
 }
 #endif
 // reduce and finish shared by the two kernels that produce the partial results
-static int launch_fused_tail(const sfm_ba_plan* p, double mu_u, double* S, double* e, double* ssq, double* part,
-                             double* kpart, const double* far_part, hipStream_t st);
+static int launch_fused_tail(const sfm_ba_plan* p, double mu_u, double* S, double* e, double* ssq, char* ws,
+                             const double* far_part, hipStream_t st);
 
 bool fz_state_applies(const sfm_ba_plan* p) {
-  return p->n_runs > 0 && p->fz_enabled && p->fz_max_range_runs <= kFzMaxRunsPerRange;
+  if (p->n_runs <= 0 || !p->fz_enabled) return false;
+  for (int c = 0; c < kFzClasses; ++c)
+    if (p->fz[c].max_range_runs > kFzMaxRunsPerRange) return false;
+  return true;
 }
 
-// The far points' share of the assembly: V^-1, eps_b of those points, g and T in the far plan's
-// workspace, and the partial results of its camera-pair blocks, which k_fused_finish adds into S.
-// A_far, xt_far, xp_far: rows of A and pixels in the far plan's observation order.
 static int launch_far_unobserved(const sfm_ba_plan* p, double mu, double* Vinv, double* eps_b, double* db,
                                  hipStream_t st) {
   if (p->far || p->n_far <= 0) return SFM_BA_OK;
@@ -845,6 +873,9 @@ static int launch_far_unobserved(const sfm_ba_plan* p, double mu, double* Vinv, 
   return check_launch_fz("k_far_unobserved");
 }
 
+// The far points' share of the assembly: V^-1, eps_b of those points, g and T in the far plan's
+// workspace, and the partial results of its camera-pair blocks, which k_fused_finish adds into S.
+// A_far, xt_far, xp_far: rows of A and pixels in the far plan's observation order.
 static int launch_far_assemble(const sfm_ba_plan* p, const double* A_far, const double* xt_far, const double* xp_far,
                                double mu, double* Vinv, double* eps_b, char* ws, hipStream_t st) {
   if (!p->far) return SFM_BA_OK;
@@ -855,13 +886,23 @@ static const double* far_partials(const sfm_ba_plan* p, const char* ws) {
   return p->far ? reinterpret_cast<const double*>(ws + p->ws_far + p->far->ws_spart) : nullptr;
 }
 
+// waves per SIMD of k_fused_state for a window width: with windows of up to six cameras the kernel fits 256
+// registers (what it spills is only reloaded when the window changes) and two waves cover each other's
+// waits (364 against 387 us on 1 800 x 1 M); from seven cameras on it spills inside the steps, and one wave
+// with 512 registers - the camera record held in them for the whole run - is the faster one (142 against 147 us)
+static int state_waves_per_simd(int slots) {
+  static const int wps_env = [] {
+    const char* v = getenv("SFM_BA_FZ_STATE_WPS");
+    return v && (v[0] == '1' || v[0] == '2') ? v[0] - '0' : 0;
+  }();
+  return wps_env ? wps_env : (slots <= 6 ? 2 : 1);
+}
+
 int launch_assemble_state(const sfm_ba_plan* p, const double* blk, const double* P, const double* X, const double* xt,
                           double mu, double mu_u, double* S, double* e, double* Vinv, double* eps_b, double* ssq, void* ws,
                           hipStream_t st) {
   if (!fz_state_applies(p)) return SFM_BA_EINVAL;
   char* base = static_cast<char*>(ws);
-  double* part = reinterpret_cast<double*>(base + p->ws_fpart);
-  double* kpart = reinterpret_cast<double*>(base + p->ws_fkey);
   if (p->far) {
     // far points: their rows of A and predictions from the state (the Jacobian kernel on the far plan's
     // observation list), their observed pixels gathered beside them
@@ -881,57 +922,62 @@ int launch_assemble_state(const sfm_ba_plan* p, const double* blk, const double*
     const int rc = launch_far_unobserved(p, mu, Vinv, eps_b, nullptr, st);
     if (rc) return rc;
   }
-  {
-    ProfScope ps(KID_FUSED_STATE, st);
-    // waves per SIMD: with windows of up to six cameras the kernel fits 256 registers (what it spills
-    // is only reloaded when the window changes) and two waves cover each other's waits (364 against
-    // 387 us on 1 800 x 1 M); from seven cameras on it spills inside the steps, and one wave with 512
-    // registers - the camera record held in them for the whole run - is the faster one (142 against 147 us)
-    static const int wps_env = [] {
-      const char* v = getenv("SFM_BA_FZ_STATE_WPS");
-      return v && (v[0] == '1' || v[0] == '2') ? v[0] - '0' : 0;
-    }();
-    const int wps_state = wps_env ? wps_env : (p->fz_slots <= 6 ? 2 : 1);
-#define FZ_LAUNCH_STATE(W, T, E)                                                                                        \
-  do {                                                                                                                  \
-    if (wps_state == 2)                                                                                                 \
-      hipLaunchKernelGGL((k_fused_state<W, T, E, 2>), dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0,   \
-                         p->d_run_cam, p->d_slot_obs, p->d_fz_pt, blk, P, X, xt, mu, Vinv, eps_b, part, p->fz_pmax,     \
-                         p->n_near, p->m);                                                                              \
-    else                                                                                                                \
-      hipLaunchKernelGGL((k_fused_state<W, T, E, 1>), dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0,   \
-                         p->d_run_cam, p->d_slot_obs, p->d_fz_pt, blk, P, X, xt, mu, Vinv, eps_b, part, p->fz_pmax,     \
-                         p->n_near, p->m);                                                                              \
+  for (int c = 0; c < kFzClasses; ++c) {
+    const FzClass& f = p->fz[c];
+    if (f.n_runs <= 0) continue;
+    double* part = reinterpret_cast<double*>(base + f.ws_part);
+    {
+      ProfScope ps(KID_FUSED_STATE, st);
+      const int wps_state = state_waves_per_simd(f.slots);
+#define FZ_ARGS dim3(f.n_ranges), dim3(64), 0, st, f.d_rng_run, f.d_run_pt0, f.d_run_cam, f.d_slot_obs, f.d_pt, blk, P, X, xt, \
+                mu, Vinv, eps_b, part, f.pmax, f.n_near, p->m
+#define FZ_LAUNCH_STATE(W, T, E)                                       \
+  do {                                                                 \
+    if (wps_state == 2)                                                \
+      hipLaunchKernelGGL((k_fused_state<W, T, E, 2, 8>), FZ_ARGS);     \
+    else                                                               \
+      hipLaunchKernelGGL((k_fused_state<W, T, E, 1, 8>), FZ_ARGS);     \
   } while (0)
-    switch (p->fz_slots) {
-      case 4: FZ_LAUNCH_STATE(4, 2, 0); break;
-      case 5: FZ_LAUNCH_STATE(5, 3, 0); break;
-      case 6: FZ_LAUNCH_STATE(6, 3, 0); break;
-      case 7: FZ_LAUNCH_STATE(7, 3, 1); break;
-      default: FZ_LAUNCH_STATE(8, 4, 0); break;
-    }
+      switch (f.slots) {
+        case 4: FZ_LAUNCH_STATE(4, 2, 0); break;
+        case 5: FZ_LAUNCH_STATE(5, 3, 0); break;
+        case 6: FZ_LAUNCH_STATE(6, 3, 0); break;
+        case 7: FZ_LAUNCH_STATE(7, 3, 1); break;
+        case 8: FZ_LAUNCH_STATE(8, 4, 0); break;
+        default: hipLaunchKernelGGL((k_fused_state<16, 7, 0, 1, 16>), FZ_ARGS); break;
+      }
 #undef FZ_LAUNCH_STATE
-  }
+#undef FZ_ARGS
+    }
 #ifdef SFMBA_FZ_STAMPS
-  fz_print_stamps();
+    fz_print_stamps();
 #endif
-  const int rc = check_launch_fz("k_fused_state");
-  if (rc) return rc;
+    const int rc = check_launch_fz("k_fused_state");
+    if (rc) return rc;
+  }
   if (!S) return SFM_BA_OK;
-  return launch_fused_tail(p, mu_u, S, e, ssq, part, kpart, far_partials(p, base), st);
+  return launch_fused_tail(p, mu_u, S, e, ssq, base, far_partials(p, base), st);
 }
 
 int launch_back_substitute_state(const sfm_ba_plan* p, const double* blk, const double* Vinv, const double* eps_b,
                                  const double* da, double* db, double* X, int update, double x_step, void* ws,
                                  hipStream_t st) {
   if (p->n_runs <= 0) return SFM_BA_EINVAL;
-  {
-    ProfScope ps(KID_BACK_STATE, st);
-    hipLaunchKernelGGL(k_back_substitute_state, dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0,
-                       p->d_run_cam, p->d_slot_obs, p->d_fz_pt, blk, Vinv, eps_b, da, db, X, update, x_step);
+  for (int c = 0; c < kFzClasses; ++c) {
+    const FzClass& f = p->fz[c];
+    if (f.n_runs <= 0) continue;
+    {
+      ProfScope ps(KID_BACK_STATE, st);
+      if (f.lanes == 8)
+        hipLaunchKernelGGL(k_back_substitute_state<8>, dim3(f.n_ranges), dim3(64), 0, st, f.d_rng_run, f.d_run_pt0, f.d_run_cam,
+                           f.d_slot_obs, f.d_pt, blk, Vinv, eps_b, da, db, X, update, x_step);
+      else
+        hipLaunchKernelGGL(k_back_substitute_state<16>, dim3(f.n_ranges), dim3(64), 0, st, f.d_rng_run, f.d_run_pt0,
+                           f.d_run_cam, f.d_slot_obs, f.d_pt, blk, Vinv, eps_b, da, db, X, update, x_step);
+    }
+    const int rc = check_launch_fz("k_back_substitute_state");
+    if (rc) return rc;
   }
-  const int rc = check_launch_fz("k_back_substitute_state");
-  if (rc) return rc;
   if (!p->far) return launch_far_unobserved(p, 1.0, nullptr, nullptr, db, st);
   // far points: from the rows the assembly left in the workspace
   const double* A_far = reinterpret_cast<const double*>(static_cast<char*>(ws) + p->ws_far_A);
@@ -942,8 +988,6 @@ int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* x
                           double mu_u, double* S, double* e, double* Vinv, double* eps_b, void* ws, hipStream_t st) {
   if (p->n_runs <= 0) return SFM_BA_OK;
   char* base = static_cast<char*>(ws);
-  double* part = reinterpret_cast<double*>(base + p->ws_fpart);
-  double* kpart = reinterpret_cast<double*>(base + p->ws_fkey);
   if (p->far) {
     double* A_far = reinterpret_cast<double*>(base + p->ws_far_A);
     double* xt_far = reinterpret_cast<double*>(base + p->ws_far_xt);
@@ -958,57 +1002,71 @@ int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* x
     const int rc = launch_far_unobserved(p, mu, Vinv, eps_b, nullptr, st);
     if (rc) return rc;
   }
-  {
-    ProfScope ps(KID_FUSED_RUNS, st);
-#define FZ_LAUNCH4(W, T, E, WPS)                                                                                    \
-  hipLaunchKernelGGL((k_fused_runs<W, T, E, WPS>), dim3(p->n_ranges), dim3(64), 0, st, p->d_rng_run, p->d_run_pt0, \
-                     p->d_slot_obs, p->d_fz_pt, A, xt, xp, mu, Vinv, eps_b, part, p->fz_pmax, p->n_near)
-#define FZ_LAUNCH(W, T, E)          \
-  do {                              \
-    if (wps == 1)                   \
-      FZ_LAUNCH4(W, T, E, 1);       \
-    else                            \
-      FZ_LAUNCH4(W, T, E, 2);       \
+  // waves per SIMD the kernel is compiled for: two (256 registers each) hide memory latency better,
+  // unless the variant then spills - a reload from scratch memory waits for every load in flight
+  static const int wps_env = [] {
+    const char* v = getenv("SFM_BA_FZ_WPS");
+    return v && (v[0] == '1' || v[0] == '2') ? v[0] - '0' : 0;
+  }();
+  const int wps = wps_env ? wps_env : 2;
+  for (int c = 0; c < kFzClasses; ++c) {
+    const FzClass& f = p->fz[c];
+    if (f.n_runs <= 0) continue;
+    double* part = reinterpret_cast<double*>(base + f.ws_part);
+    {
+      ProfScope ps(KID_FUSED_RUNS, st);
+#define FZ_ARGS dim3(f.n_ranges), dim3(64), 0, st, f.d_rng_run, f.d_run_pt0, f.d_slot_obs, f.d_pt, A, xt, xp, mu, Vinv, eps_b, \
+                part, f.pmax, f.n_near
+#define FZ_LAUNCH(W, T, E)                                          \
+  do {                                                              \
+    if (wps == 1)                                                   \
+      hipLaunchKernelGGL((k_fused_runs<W, T, E, 1, 8>), FZ_ARGS);   \
+    else                                                            \
+      hipLaunchKernelGGL((k_fused_runs<W, T, E, 2, 8>), FZ_ARGS);   \
   } while (0)
-    // waves per SIMD the kernel is compiled for: two (256 registers each) hide memory latency better,
-    // unless the variant then spills - a reload from scratch memory waits for every load in flight
-    static const int wps_env = [] {
-      const char* v = getenv("SFM_BA_FZ_WPS");
-      return v && (v[0] == '1' || v[0] == '2') ? v[0] - '0' : 0;
-    }();
-    const int wps = wps_env ? wps_env : 2;
-    switch (p->fz_slots) {
-      case 4: FZ_LAUNCH(4, 2, 0); break;
-      case 5: FZ_LAUNCH(5, 3, 0); break;
-      case 6: FZ_LAUNCH(6, 3, 0); break;
-      case 7: FZ_LAUNCH(7, 3, 1); break;
-      default: FZ_LAUNCH(8, 4, 0); break;
-    }
+      switch (f.slots) {
+        case 4: FZ_LAUNCH(4, 2, 0); break;
+        case 5: FZ_LAUNCH(5, 3, 0); break;
+        case 6: FZ_LAUNCH(6, 3, 0); break;
+        case 7: FZ_LAUNCH(7, 3, 1); break;
+        case 8: FZ_LAUNCH(8, 4, 0); break;
+        default: hipLaunchKernelGGL((k_fused_runs<16, 7, 0, 1, 16>), FZ_ARGS); break;
+      }
 #undef FZ_LAUNCH
-#undef FZ_LAUNCH4
-  }
+#undef FZ_ARGS
+    }
 #ifdef SFMBA_FZ_STAMPS
-  fz_print_stamps();
+    fz_print_stamps();
 #endif
-  int rc = check_launch_fz("k_fused_runs");
-  if (rc) return rc;
+    const int rc = check_launch_fz("k_fused_runs");
+    if (rc) return rc;
+  }
   if (!S) return SFM_BA_OK;
-  return launch_fused_tail(p, mu_u, S, e, nullptr, part, kpart, far_partials(p, base), st);
+  return launch_fused_tail(p, mu_u, S, e, nullptr, base, far_partials(p, base), st);
 }
 
-static int launch_fused_tail(const sfm_ba_plan* p, double mu_u, double* S, double* e, double* ssq, double* part,
-                             double* kpart, const double* far_part, hipStream_t st) {
-  const int64_t stride = fz_part_stride(p->fz_slots);
-  {
-    ProfScope ps(KID_FUSED_REDUCE, st);
-    hipLaunchKernelGGL(k_fused_reduce, dim3(p->n_keys, 3), dim3(256), 0, st, p->d_key_run, stride, part, kpart);
+static int launch_fused_tail(const sfm_ba_plan* p, double mu_u, double* S, double* e, double* ssq, char* ws,
+                             const double* far_part, hipStream_t st) {
+  const double* kpart[kFzClasses] = {nullptr, nullptr};
+  for (int c = 0; c < kFzClasses; ++c) {
+    const FzClass& f = p->fz[c];
+    if (f.n_runs <= 0) continue;
+    double* part = reinterpret_cast<double*>(ws + f.ws_part);
+    double* kp = reinterpret_cast<double*>(ws + f.ws_key);
+    kpart[c] = kp;
+    const int64_t stride = fz_part_stride(f.slots);
+    {
+      ProfScope ps(KID_FUSED_REDUCE, st);
+      hipLaunchKernelGGL(k_fused_reduce, dim3(f.n_keys, c == 0 ? 3 : 8), dim3(256), 0, st, f.d_key_run, stride, part, kp);
+    }
+    const int rc = check_launch_fz("k_fused_reduce");
+    if (rc) return rc;
   }
-  int rc = check_launch_fz("k_fused_reduce");
-  if (rc) return rc;
   if (p->n_blocks > 0) {
     ProfScope ps(KID_FUSED_FINISH, st);
     hipLaunchKernelGGL(k_fused_finish, dim3(p->n_blocks), dim3(64), 0, st, p->d_blk_j, p->d_blk_k, p->d_fb_ptr,
-                       p->d_fb_ent, p->d_fb_far_part, p->d_fb_far_cnt, p->fz_slots, kpart, far_part, mu_u, p->m, S, e, ssq);
+                       p->d_fb_ent, p->d_fb_far_part, p->d_fb_far_cnt, p->fz[0].slots, p->fz[1].slots, kpart[0], kpart[1],
+                       far_part, mu_u, p->m, S, e, ssq);
   }
   return check_launch_fz("k_fused_finish");
 }

@@ -43,11 +43,14 @@ void plan_set_workspace(sfm_ba_plan* p) {
   off = align256(off + (int64_t)std::max(p->n_items, 1) * SFM_BA_CAM_RED * (int64_t)sizeof(double));
   p->ws_spart = off;
   off = align256(off + (int64_t)std::max(p->n_parts, 1) * kPairPartStride * (int64_t)sizeof(double));
-  // fused point-major assembly: one partial result per run, one per window
-  p->ws_fpart = off;
-  off = align256(off + (int64_t)p->n_runs * fz_part_stride(p->fz_slots) * (int64_t)sizeof(double));
-  p->ws_fkey = off;
-  off = align256(off + (int64_t)p->n_keys * fz_part_stride(p->fz_slots) * (int64_t)sizeof(double));
+  // fused point-major assembly: per class one partial result per run, one per window
+  for (int c = 0; c < kFzClasses; ++c) {
+    FzClass& f = p->fz[c];
+    f.ws_part = off;
+    off = align256(off + (int64_t)f.n_runs * (f.slots ? fz_part_stride(f.slots) : 0) * (int64_t)sizeof(double));
+    f.ws_key = off;
+    off = align256(off + (int64_t)f.n_keys * (f.slots ? fz_part_stride(f.slots) : 0) * (int64_t)sizeof(double));
+  }
   p->ws_fzero = off;  // a row of zeros
   off = align256(off + 256);
   // far points: their rows of A, observed and predicted pixels in the far plan's observation order,
@@ -74,11 +77,16 @@ extern "C" void sfm_ba_plan_destroy(sfm_ba_plan* p) {
   void* ptrs[] = {p->d_pt_ptr,   p->d_perm,     p->d_slot_cam, p->d_tp_ptr,  p->d_grp_pt,  p->d_cam_obs, p->d_pair_entry,
                   p->d_item_cam, p->d_item_beg, p->d_item_end, p->d_cam_item_ptr, p->d_blk_j, p->d_blk_k,
                   p->d_entries,  p->d_pit_blk,  p->d_pit_beg,  p->d_pit_end, p->d_pit_part, p->d_mb_blk,
-                  p->d_mb_part,  p->d_mb_cnt,   p->d_fz_pt,    p->d_slot_obs, p->d_run_pt0, p->d_run_key,
-                  p->d_run_cam,  p->d_rng_run,  p->d_key_cam,  p->d_key_run, p->d_fb_ptr,  p->d_fb_ent,
+                  p->d_mb_part,  p->d_mb_cnt,   p->d_fb_ptr,   p->d_fb_ent,
                   p->d_fb_far_part, p->d_fb_far_cnt, p->d_far_pt, p->d_far_obs, p->d_far_cam, p->d_far_lpt, p->d_far_gpt};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
+  for (int c = 0; c < kFzClasses; ++c) {
+    const FzClass& f = p->fz[c];
+    void* fp[] = {f.d_pt, f.d_slot_obs, f.d_run_pt0, f.d_run_key, f.d_run_cam, f.d_rng_run, f.d_key_cam, f.d_key_run};
+    for (void* q : fp)
+      if (q) (void)hipFree(q);
+  }
   sfm_ba_plan_destroy(p->far);
   delete p;
 }
@@ -282,91 +290,98 @@ int build_host(const int32_t* cam_idx, const int32_t* pt_idx, int64_t N, int32_t
   }
 
   // ---- near points of the fused point-major assembly, far points (same rules as the device builder) ----
-  std::vector<int32_t> fz_pt, slot_obs, run_pt0, run_key, run_cam, rng_run, key_cam, key_run, fb_ptr, fb_ent, fb_far_part,
-      fb_far_cnt, far_pt, far_obs, far_cam, far_lpt, far_gpt;
+  // per class: point ids by position, slot table, runs, windows
+  struct HostClass {
+    std::vector<int32_t> pt, slot_obs, run_pt0, run_key, run_cam, rng_run, key_cam, key_run;
+  } hc[kFzClasses];
+  std::vector<int32_t> fb_ptr, fb_ent, fb_far_part, fb_far_cnt, far_pt, far_obs, far_cam, far_lpt, far_gpt;
   // (a list that names a (camera, point) pair twice - accepted only without checks - stays on the
   // camera-pair path, which adds both; the slot table of the fused path has room for one)
   if (!(flags & kPlanNoFused) && !nonunique) {
     int64_t obs_by_k[9] = {0}, obs_by_span[9] = {0};
-    bool empty_point = false;
     for (int32_t i = 0; i < n; ++i) {
       const int32_t k = pt_ptr[i + 1] - pt_ptr[i];
-      if (k == 0) empty_point = true;
       if (k < 1 || k > 8) continue;
       obs_by_k[k] += k;
       const int32_t span = slot_cam[pt_ptr[i + 1] - 1] - slot_cam[pt_ptr[i]] + 1;
       if (span <= 8) obs_by_span[span] += k;
     }
-    const int slots = fz_choose_slots(obs_by_k, obs_by_span);
-    std::vector<int32_t> desc, cand, near;
-    std::vector<uint64_t> key;
-    if (slots > 0) {
-      desc.assign((size_t)n * 8, -1);
-      key.assign((size_t)n, 0);
+    std::vector<int32_t> cls_of((size_t)n, -1);  // class in which the point is near
+    for (int c = 0; c < kFzClasses; ++c) {
+      const int slots = c == 0 ? fz_choose_slots(obs_by_k, obs_by_span) : 16;
+      if (slots <= 0) continue;
+      const int lanes = fz_lanes(slots);
+      // candidates: the points no earlier class took, sorted by the key of their window (ties: ascending id)
+      std::vector<int32_t> desc((size_t)n * lanes, -1), cand, near;
+      std::vector<uint64_t> key((size_t)n, 0);
       for (int32_t i = 0; i < n; ++i)
-        if (fz_point_window(slot_cam.data() + pt_ptr[i], pt_ptr[i + 1] - pt_ptr[i], slots, m, &desc[(size_t)8 * i], &key[i]))
+        if (cls_of[i] < 0 && fz_point_window(slot_cam.data() + pt_ptr[i], pt_ptr[i + 1] - pt_ptr[i], slots, lanes, m,
+                                             &desc[(size_t)lanes * i], &key[i]))
           cand.push_back(i);
       std::stable_sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
-    }
-    auto same_window = [&](int32_t a, int32_t b) {
-      return memcmp(&desc[(size_t)8 * a], &desc[(size_t)8 * b], 8 * sizeof(int32_t)) == 0;
-    };
-    // windows = maximal stretches of equal camera lists in the sorted order; short ones are given up
-    for (size_t q = 0; q < cand.size();) {
-      size_t r = q + 1;
-      while (r < cand.size() && same_window(cand[q], cand[r])) ++r;
-      if (r - q >= (size_t)kFzMinWindowPoints) near.insert(near.end(), cand.begin() + q, cand.begin() + r);
-      q = r;
-    }
-    const int32_t n_near = (int32_t)near.size();
-    const int32_t pmax = fz_pmax_for(n_near);
-    for (int32_t q = 0; q < n_near; ++q) {
-      const bool new_window = q == 0 || !same_window(near[q], near[q - 1]);
-      if (new_window) {
-        key_run.push_back((int32_t)run_pt0.size());
-        key_cam.insert(key_cam.end(), &desc[(size_t)8 * near[q]], &desc[(size_t)8 * near[q]] + 8);
+      auto same_window = [&](int32_t a, int32_t b) {
+        return memcmp(&desc[(size_t)lanes * a], &desc[(size_t)lanes * b], lanes * sizeof(int32_t)) == 0;
+      };
+      // windows = maximal stretches of equal camera lists in the sorted order; short ones are given up
+      for (size_t q = 0; q < cand.size();) {
+        size_t r = q + 1;
+        while (r < cand.size() && same_window(cand[q], cand[r])) ++r;
+        if (r - q >= (size_t)fz_min_window_points(c)) near.insert(near.end(), cand.begin() + q, cand.begin() + r);
+        q = r;
       }
-      if (new_window || q % pmax == 0) {
-        run_pt0.push_back(q);
-        run_key.push_back((int32_t)key_run.size() - 1);
-        const int32_t* d = &desc[(size_t)8 * near[q]];
-        for (int s = 0; s < 8; ++s) run_cam.push_back(d[s] >= 0 ? d[s] : d[0]);
+      const int32_t n_near = (int32_t)near.size();
+      const int32_t pmax = fz_pmax_for(n_near);
+      HostClass& h = hc[c];
+      for (int32_t q = 0; q < n_near; ++q) {
+        const bool new_window = q == 0 || !same_window(near[q], near[q - 1]);
+        if (new_window) {
+          h.key_run.push_back((int32_t)h.run_pt0.size());
+          h.key_cam.insert(h.key_cam.end(), &desc[(size_t)lanes * near[q]], &desc[(size_t)lanes * near[q]] + lanes);
+        }
+        if (new_window || q % pmax == 0) {
+          h.run_pt0.push_back(q);
+          h.run_key.push_back((int32_t)h.key_run.size() - 1);
+          const int32_t* d = &desc[(size_t)lanes * near[q]];
+          for (int s = 0; s < lanes; ++s) h.run_cam.push_back(d[s] >= 0 ? d[s] : d[0]);
+        }
       }
-    }
-    const int32_t n_runs = (int32_t)run_pt0.size();
-    int64_t n_far_obs = N;
-    for (int32_t q = 0; q < n_near; ++q) n_far_obs -= pt_ptr[near[q] + 1] - pt_ptr[near[q]];
-    // (points without observations - allowed on plans built with size hints - go with the far points)
-    (void)empty_point;
-    (void)n_far_obs;
-    if (fz_worthwhile(n, n_near, n_runs)) {
-      p->fz_slots = slots;
-      p->fz_pmax = pmax;
-      p->n_near = n_near;
-      p->n_runs = n_runs;
-      p->n_keys = (int32_t)key_run.size();
-      key_run.push_back(n_runs);
-      run_pt0.push_back(n_near);
-      p->n_ranges = (n_near + pmax - 1) / pmax;
-      rng_run.assign(p->n_ranges + 1, n_runs);
+      const int32_t n_runs = (int32_t)h.run_pt0.size();
+      if (!fz_worthwhile(c, n, n_near, n_runs)) {
+        h = HostClass();
+        continue;
+      }
+      FzClass& f = p->fz[c];
+      f.slots = slots;
+      f.lanes = lanes;
+      f.pmax = pmax;
+      f.n_near = n_near;
+      f.n_runs = n_runs;
+      f.n_keys = (int32_t)h.key_run.size();
+      p->n_runs += n_runs;
+      h.key_run.push_back(n_runs);
+      h.run_pt0.push_back(n_near);
+      f.n_ranges = (n_near + pmax - 1) / pmax;
+      h.rng_run.assign(f.n_ranges + 1, n_runs);
       for (int32_t r = n_runs - 1; r >= 0; --r)
-        if (run_pt0[r] % pmax == 0) rng_run[run_pt0[r] / pmax] = r;
-      for (int32_t g = 0; g < p->n_ranges; ++g)
-        p->fz_max_range_runs = std::max(p->fz_max_range_runs, rng_run[g + 1] - rng_run[g]);
-      for (int32_t r = 0; r < n_runs; ++r) p->n_steps += (run_pt0[r + 1] - run_pt0[r] + 7) / 8;
-      fz_pt = near;
-      std::vector<int32_t> pos_of((size_t)n, -1);
-      for (int32_t q = 0; q < n_near; ++q) pos_of[near[q]] = q;
-      slot_obs.assign((size_t)n_near * kFzLanesPerPoint, -1);
+        if (h.run_pt0[r] % pmax == 0) h.rng_run[h.run_pt0[r] / pmax] = r;
+      for (int32_t g = 0; g < f.n_ranges; ++g) f.max_range_runs = std::max(f.max_range_runs, h.rng_run[g + 1] - h.rng_run[g]);
+      const int pps = 64 / lanes;  // points per step
+      for (int32_t r = 0; r < n_runs; ++r) f.n_steps += (h.run_pt0[r + 1] - h.run_pt0[r] + pps - 1) / pps;
+      h.pt = near;
+      h.slot_obs.assign((size_t)n_near * lanes, -1);
       for (int32_t q = 0; q < n_near; ++q) {
         const int32_t i = near[q];
+        cls_of[i] = c;
         for (int32_t s = pt_ptr[i]; s < pt_ptr[i + 1]; ++s)
-          slot_obs[(size_t)q * kFzLanesPerPoint + fz_slot_of(&desc[(size_t)8 * i], slot_cam[s])] = perm[s];
+          h.slot_obs[(size_t)q * lanes + fz_slot_of(&desc[(size_t)lanes * i], lanes, slot_cam[s])] = perm[s];
       }
-      // far points and their observations
+    }
+    if (p->n_runs > 0) {
+      // far points (those no class took, among them the points without observations that plans built with
+      // size hints allow) and their observations
       std::vector<int32_t> far_num((size_t)n, -1);
       for (int32_t i = 0; i < n; ++i)
-        if (pos_of[i] < 0) {
+        if (cls_of[i] < 0) {
           far_num[i] = (int32_t)far_pt.size();
           far_pt.push_back(i);
         }
@@ -388,28 +403,31 @@ int build_host(const int32_t* cam_idx, const int32_t* pt_idx, int64_t N, int32_t
           return rc_far;
         }
       }
-      // what the finishing kernel adds up for every block: the windows that hold both cameras (ascending),
-      // then the far plan's partial results
+      // what the finishing kernel adds up for every block: the windows that hold both cameras (class 0 first,
+      // ascending), then the far plan's partial results
       std::vector<int32_t> blk_of((size_t)m * m, -1);
       for (int32_t b = 0; b < p->n_blocks; ++b) blk_of[(size_t)blk_j[b] * m + blk_k[b]] = b;
       fb_ptr.assign((size_t)p->n_blocks + 1, 0);
       for (int pass = 0; pass < 2; ++pass) {
         std::vector<int32_t> fill(fb_ptr.begin(), fb_ptr.end() - 1);
-        for (int32_t q = 0; q < p->n_keys; ++q)
-          for (int a = 0; a < 8; ++a) {
-            const int32_t ca = key_cam[(size_t)8 * q + a];
-            if (ca < 0) continue;
-            for (int b = a; b < 8; ++b) {
-              const int32_t cb = key_cam[(size_t)8 * q + b];
-              if (cb < 0) continue;
-              const int32_t id = blk_of[(size_t)ca * m + cb];
-              if (id < 0) continue;
-              if (pass == 0)
-                ++fb_ptr[(size_t)id + 1];
-              else
-                fb_ent[(size_t)fill[id]++] = (q << 6) | (a << 3) | b;
+        for (int c = 0; c < kFzClasses; ++c) {
+          const int lanes = p->fz[c].lanes;
+          for (int32_t q = 0; q < p->fz[c].n_keys; ++q)
+            for (int a = 0; a < lanes; ++a) {
+              const int32_t ca = hc[c].key_cam[(size_t)lanes * q + a];
+              if (ca < 0) continue;
+              for (int b = a; b < lanes; ++b) {
+                const int32_t cb = hc[c].key_cam[(size_t)lanes * q + b];
+                if (cb < 0) continue;
+                const int32_t id = blk_of[(size_t)ca * m + cb];
+                if (id < 0) continue;
+                if (pass == 0)
+                  ++fb_ptr[(size_t)id + 1];
+                else
+                  fb_ent[(size_t)fill[id]++] = fz_fb_pack(c, q, a, b);
+              }
             }
-          }
+        }
         if (pass == 0) {
           for (int32_t b = 0; b < p->n_blocks; ++b) fb_ptr[(size_t)b + 1] += fb_ptr[b];
           fb_ent.resize((size_t)fb_ptr[p->n_blocks]);
@@ -454,14 +472,17 @@ int build_host(const int32_t* cam_idx, const int32_t* pt_idx, int64_t N, int32_t
   up(mb_part, &p->d_mb_part);
   up(mb_cnt, &p->d_mb_cnt);
   if (p->n_runs > 0) {
-    up(fz_pt, &p->d_fz_pt);
-    up(slot_obs, &p->d_slot_obs);
-    up(run_pt0, &p->d_run_pt0);
-    up(run_key, &p->d_run_key);
-    up(run_cam, &p->d_run_cam);
-    up(rng_run, &p->d_rng_run);
-    up(key_cam, &p->d_key_cam);
-    up(key_run, &p->d_key_run);
+    for (int c = 0; c < kFzClasses; ++c) {
+      if (p->fz[c].n_runs <= 0) continue;
+      up(hc[c].pt, &p->fz[c].d_pt);
+      up(hc[c].slot_obs, &p->fz[c].d_slot_obs);
+      up(hc[c].run_pt0, &p->fz[c].d_run_pt0);
+      up(hc[c].run_key, &p->fz[c].d_run_key);
+      up(hc[c].run_cam, &p->fz[c].d_run_cam);
+      up(hc[c].rng_run, &p->fz[c].d_rng_run);
+      up(hc[c].key_cam, &p->fz[c].d_key_cam);
+      up(hc[c].key_run, &p->fz[c].d_key_run);
+    }
     up(fb_ptr, &p->d_fb_ptr);
     up(fb_ent, &p->d_fb_ent);
     up(fb_far_part, &p->d_fb_far_part);
@@ -508,7 +529,21 @@ extern "C" int sfm_ba_plan_read(const sfm_ba_plan* p, int field, void* h_dst, in
   if (!p || !bytes_out) return SFM_BA_EINVAL;
   const void* src = nullptr;
   int64_t count = 0, width = sizeof(int32_t);
+  // fields 21..28 belong to class 0 of the near points, 121..128 to class 1
+  const int cls = field >= 100 ? 1 : 0;
+  const FzClass& f = p->fz[cls];
+  const bool on = f.n_runs > 0;
+  if (field >= 100) field -= 100;
+  if (cls == 1 && (field < 21 || field > 28)) return SFM_BA_EINVAL;
   switch (field) {
+    case 21: src = f.d_run_pt0; count = on ? f.n_runs + 1 : 0; break;
+    case 22: src = f.d_run_key; count = f.n_runs; break;
+    case 23: src = f.d_slot_obs; count = (int64_t)f.n_near * f.lanes; break;
+    case 24: src = f.d_key_cam; count = (int64_t)f.n_keys * f.lanes; break;
+    case 25: src = f.d_key_run; count = on ? f.n_keys + 1 : 0; break;
+    case 26: src = f.d_rng_run; count = on ? f.n_ranges + 1 : 0; break;
+    case 27: src = f.d_pt; count = f.n_near; break;
+    case 28: src = f.d_run_cam; count = (int64_t)f.n_runs * f.lanes; break;
     case 0: src = p->d_pt_ptr; count = p->n + 1; break;
     case 1: src = p->d_perm; count = p->n_obs; break;
     case 2: src = p->d_slot_cam; count = p->n_obs; break;
@@ -530,14 +565,6 @@ extern "C" int sfm_ba_plan_read(const sfm_ba_plan* p, int field, void* h_dst, in
     case 18: src = p->d_mb_blk; count = p->n_multi; break;
     case 19: src = p->d_mb_part; count = p->n_multi; break;
     case 20: src = p->d_mb_cnt; count = p->n_multi; break;
-    case 21: src = p->d_run_pt0; count = p->n_runs > 0 ? p->n_runs + 1 : 0; break;
-    case 22: src = p->d_run_key; count = p->n_runs; break;
-    case 23: src = p->d_slot_obs; count = (int64_t)p->n_near * kFzLanesPerPoint; break;
-    case 24: src = p->d_key_cam; count = (int64_t)p->n_keys * 8; break;
-    case 25: src = p->d_key_run; count = p->n_runs > 0 ? p->n_keys + 1 : 0; break;
-    case 26: src = p->d_rng_run; count = p->n_runs > 0 ? p->n_ranges + 1 : 0; break;
-    case 27: src = p->d_fz_pt; count = p->n_near; break;
-    case 28: src = p->d_run_cam; count = (int64_t)p->n_runs * 8; break;
     case 29: src = p->d_fb_ptr; count = p->n_runs > 0 ? p->n_blocks + 1 : 0; break;
     case 30: src = p->d_fb_ent; count = p->n_fb; break;
     case 31: src = p->d_fb_far_part; count = p->n_runs > 0 ? p->n_blocks : 0; break;
@@ -562,16 +589,20 @@ extern "C" int32_t sfm_ba_plan_half_bandwidth(const sfm_ba_plan* p) {
   return p ? 7 * p->max_cam_dist + 6 : -1;
 }
 
-extern "C" int sfm_ba_plan_fused_info(const sfm_ba_plan* p, int32_t info[8]) {
+extern "C" int sfm_ba_plan_fused_info(const sfm_ba_plan* p, int32_t info[16]) {
   if (!p || !info) return SFM_BA_EINVAL;
-  info[0] = p->n_runs > 0 && p->fz_enabled ? 1 : 0;
-  info[1] = p->fz_slots;
-  info[2] = p->n_near;
-  info[3] = p->fz_pmax;
-  info[4] = p->n_runs;
-  info[5] = p->n_keys;
-  info[6] = p->n_steps;
-  info[7] = p->n_ranges;
+  for (int c = 0; c < kFzClasses; ++c) {
+    const FzClass& f = p->fz[c];
+    int32_t* o = info + 8 * c;
+    o[0] = f.n_runs > 0 && p->fz_enabled ? 1 : 0;
+    o[1] = f.slots;
+    o[2] = f.n_near;
+    o[3] = f.pmax;
+    o[4] = f.n_runs;
+    o[5] = f.n_keys;
+    o[6] = f.n_steps;
+    o[7] = f.n_ranges;
+  }
   return SFM_BA_OK;
 }
 

@@ -297,18 +297,19 @@ __global__ void k_fz_hist(const int32_t* __restrict__ pt_ptr, const int32_t* __r
   if (threadIdx.x < 18 && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
 }
 
-// window and sort key of every point; a point that fits no window gets the largest key
-__global__ void k_fz_desc(const int32_t* __restrict__ pt_ptr, const int32_t* __restrict__ slot_cam, int32_t n, int slots,
-                          int32_t m, int32_t* __restrict__ desc, uint64_t* __restrict__ key, int32_t* __restrict__ ident,
+// window and sort key of every point that no earlier class took; a point that fits no window of this
+// class gets the largest key
+__global__ void k_fz_desc(const int32_t* __restrict__ pt_ptr, const int32_t* __restrict__ slot_cam,
+                          const int32_t* __restrict__ taken, int32_t n, int slots, int lanes, int32_t m,
+                          int32_t* __restrict__ desc, uint64_t* __restrict__ key, int32_t* __restrict__ ident,
                           int32_t* __restrict__ n_cand) {
   const int32_t i = blockIdx.x * kT + threadIdx.x;
   bool ok = false;
   if (i < n) {
-    int32_t d[8];
+    int32_t d[kFzMaxLanes];
     uint64_t k64 = 0;
-    ok = fz_point_window(slot_cam + pt_ptr[i], pt_ptr[i + 1] - pt_ptr[i], slots, m, d, &k64);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) desc[(int64_t)8 * i + s] = ok ? d[s] : -1;
+    ok = taken[i] < 0 && fz_point_window(slot_cam + pt_ptr[i], pt_ptr[i + 1] - pt_ptr[i], slots, lanes, m, d, &k64);
+    for (int s = 0; s < lanes; ++s) desc[(int64_t)lanes * i + s] = ok ? d[s] : -1;
     key[i] = ok ? k64 : (uint64_t(1) << 33);
     ident[i] = i;
   }
@@ -316,19 +317,18 @@ __global__ void k_fz_desc(const int32_t* __restrict__ pt_ptr, const int32_t* __r
   if (any && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(any)) atomicAdd(n_cand, (int32_t)__builtin_popcountll(any));
 }
 
-__device__ inline bool fz_same_window(const int32_t* __restrict__ desc, int32_t a, int32_t b) {
+__device__ inline bool fz_same_window(const int32_t* __restrict__ desc, int lanes, int32_t a, int32_t b) {
   bool same = true;
-#pragma unroll
-  for (int s = 0; s < 8; ++s) same = same && desc[(int64_t)8 * a + s] == desc[(int64_t)8 * b + s];
+  for (int s = 0; s < lanes; ++s) same = same && desc[(int64_t)lanes * a + s] == desc[(int64_t)lanes * b + s];
   return same;
 }
 
 // candidates in sorted order: a window starts where the camera list changes (element n_cand: 0)
-__global__ void k_fz_win_flags(const int32_t* __restrict__ sorted_pt, const int32_t* __restrict__ desc, int32_t n_cand,
-                               int32_t* __restrict__ flag) {
+__global__ void k_fz_win_flags(const int32_t* __restrict__ sorted_pt, const int32_t* __restrict__ desc, int lanes,
+                               int32_t n_cand, int32_t* __restrict__ flag) {
   const int32_t q = blockIdx.x * kT + threadIdx.x;
   if (q > n_cand) return;
-  flag[q] = q < n_cand && (q == 0 || !fz_same_window(desc, sorted_pt[q], sorted_pt[q - 1])) ? 1 : 0;
+  flag[q] = q < n_cand && (q == 0 || !fz_same_window(desc, lanes, sorted_pt[q], sorted_pt[q - 1])) ? 1 : 0;
 }
 
 // first candidate of every window (element n_win: n_cand)
@@ -342,27 +342,27 @@ __global__ void k_fz_win_starts(const int32_t* __restrict__ flag, const int32_t*
     wstart[wid_excl[q]] = q;
 }
 
-// candidates and windows that stay: windows with at least kFzMinWindowPoints points (elements n_cand / n_win: 0)
+// candidates and windows that stay: windows with at least min_pts points (elements n_cand / n_win: 0)
 __global__ void k_fz_keep(const int32_t* __restrict__ flag, const int32_t* __restrict__ wid_excl,
-                          const int32_t* __restrict__ wstart, int32_t n_cand, int32_t n_win, int32_t* __restrict__ keep,
-                          int32_t* __restrict__ wkeep) {
+                          const int32_t* __restrict__ wstart, int32_t n_cand, int32_t n_win, int32_t min_pts,
+                          int32_t* __restrict__ keep, int32_t* __restrict__ wkeep) {
   const int32_t q = blockIdx.x * kT + threadIdx.x;
   if (q <= n_cand) {
     int32_t kp = 0;
     if (q < n_cand) {
       const int32_t w = wid_excl[q] + flag[q] - 1;
-      kp = wstart[w + 1] - wstart[w] >= kFzMinWindowPoints ? 1 : 0;
+      kp = wstart[w + 1] - wstart[w] >= min_pts ? 1 : 0;
     }
     keep[q] = kp;
   }
-  if (q <= n_win) wkeep[q] = q < n_win && wstart[q + 1] - wstart[q] >= kFzMinWindowPoints ? 1 : 0;
+  if (q <= n_win) wkeep[q] = q < n_win && wstart[q + 1] - wstart[q] >= min_pts ? 1 : 0;
 }
 
 // near points at their positions: point id, window, whether a window / a run starts there, position of every point
 __global__ void k_fz_place(const int32_t* __restrict__ sorted_pt, const int32_t* __restrict__ flag,
                            const int32_t* __restrict__ wid_excl, const int32_t* __restrict__ keep,
                            const int32_t* __restrict__ newpos, const int32_t* __restrict__ newwid,
-                           const int32_t* __restrict__ desc, int32_t n_cand, int32_t n_near, int32_t pmax,
+                           const int32_t* __restrict__ desc, int lanes, int32_t n_cand, int32_t n_near, int32_t pmax,
                            int32_t* __restrict__ fz_pt, int32_t* __restrict__ near_pos, int32_t* __restrict__ pos_key,
                            int32_t* __restrict__ win_start, int32_t* __restrict__ run_flag, int32_t* __restrict__ key_cam) {
   const int32_t q = blockIdx.x * kT + threadIdx.x;
@@ -375,15 +375,13 @@ __global__ void k_fz_place(const int32_t* __restrict__ sorted_pt, const int32_t*
   pos_key[pos] = key;
   win_start[pos] = flag[q];
   run_flag[pos] = (flag[q] || pos % pmax == 0) ? 1 : 0;
-  if (flag[q]) {
-#pragma unroll
-    for (int s = 0; s < 8; ++s) key_cam[(int64_t)8 * key + s] = desc[(int64_t)8 * i + s];
-  }
+  if (flag[q])
+    for (int s = 0; s < lanes; ++s) key_cam[(int64_t)lanes * key + s] = desc[(int64_t)lanes * i + s];
 }
 
 __global__ void k_fz_runs(const int32_t* __restrict__ run_flag, const int32_t* __restrict__ rid,
                           const int32_t* __restrict__ win_start, const int32_t* __restrict__ pos_key,
-                          const int32_t* __restrict__ key_cam, int32_t n_near, int32_t n_keys, int32_t pmax,
+                          const int32_t* __restrict__ key_cam, int lanes, int32_t n_near, int32_t n_keys, int32_t pmax,
                           int32_t* __restrict__ run_pt0, int32_t* __restrict__ run_key, int32_t* __restrict__ run_cam,
                           int32_t* __restrict__ key_run, int32_t* __restrict__ rng_run) {
   const int32_t pos = blockIdx.x * kT + threadIdx.x;
@@ -399,20 +397,20 @@ __global__ void k_fz_runs(const int32_t* __restrict__ run_flag, const int32_t* _
   const int32_t r = rid[pos], key = pos_key[pos];
   run_pt0[r] = pos;
   run_key[r] = key;
-  const int32_t first = key_cam[(int64_t)8 * key];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const int32_t c = key_cam[(int64_t)8 * key + s];
-    run_cam[(int64_t)8 * r + s] = c >= 0 ? c : first;
+  const int32_t first = key_cam[(int64_t)lanes * key];
+  for (int s = 0; s < lanes; ++s) {
+    const int32_t c = key_cam[(int64_t)lanes * key + s];
+    run_cam[(int64_t)lanes * r + s] = c >= 0 ? c : first;
   }
   if (win_start[pos]) key_run[key] = r;
   if (pos % pmax == 0) rng_run[pos / pmax] = r;
 }
 
-// observation of every (position, window slot)
+// observation of every (position, window slot) of one class; the points of the class are marked as taken
 __global__ void k_slot_obs_fill(const int32_t* __restrict__ slot_pt, const int32_t* __restrict__ slot_cam,
                                 const int32_t* __restrict__ perm, const int32_t* __restrict__ near_pos,
-                                const int32_t* __restrict__ desc, int64_t N, int32_t* __restrict__ slot_obs) {
+                                const int32_t* __restrict__ desc, int lanes, int cls, int64_t N,
+                                int32_t* __restrict__ slot_obs, int32_t* __restrict__ taken) {
   const int64_t s = (int64_t)blockIdx.x * kT + threadIdx.x;
   if (s >= N) return;
   const int32_t i = slot_pt[s];
@@ -420,18 +418,18 @@ __global__ void k_slot_obs_fill(const int32_t* __restrict__ slot_pt, const int32
   if (pos < 0) return;
   const int32_t c = slot_cam[s];
   int sl = 0;
-#pragma unroll
-  for (int q = 0; q < 8; ++q)
-    if (desc[(int64_t)8 * i + q] == c) sl = q;
-  slot_obs[(int64_t)pos * kFzLanesPerPoint + sl] = perm[s];
+  for (int q = 0; q < lanes; ++q)
+    if (desc[(int64_t)lanes * i + q] == c) sl = q;
+  slot_obs[(int64_t)pos * lanes + sl] = perm[s];
+  taken[i] = cls;  // (every slot of the point writes the same value)
 }
 
 // far points (element n: 0) and far observations (element N: 0), for the prefix sums that number them
-__global__ void k_far_flags(const int32_t* __restrict__ near_pos, const int32_t* __restrict__ pt, int32_t n, int64_t N,
+__global__ void k_far_flags(const int32_t* __restrict__ taken, const int32_t* __restrict__ pt, int32_t n, int64_t N,
                             int32_t* __restrict__ pflag, int32_t* __restrict__ oflag) {
   const int64_t i = (int64_t)blockIdx.x * kT + threadIdx.x;
-  if (i <= n) pflag[i] = i < n && near_pos[i] < 0 ? 1 : 0;
-  if (i <= N) oflag[i] = i < N && near_pos[pt[i]] < 0 ? 1 : 0;
+  if (i <= n) pflag[i] = i < n && taken[i] < 0 ? 1 : 0;
+  if (i <= N) oflag[i] = i < N && taken[pt[i]] < 0 ? 1 : 0;
 }
 
 __global__ void k_far_fill(const int32_t* __restrict__ pflag, const int32_t* __restrict__ pnum,
@@ -450,25 +448,27 @@ __global__ void k_far_fill(const int32_t* __restrict__ pflag, const int32_t* __r
   }
 }
 
-// what the finishing kernel adds for every block: one candidate per (window, slot a <= slot b); its sort
-// key is the block of the two cameras (nb: none - a slot without a camera, or a pair without a shared point)
-__global__ void k_fb_candidates(const int32_t* __restrict__ key_cam, int32_t n_keys, const int32_t* __restrict__ seen,
-                                const int32_t* __restrict__ blk_of, int32_t m, int32_t nb, uint32_t* __restrict__ key,
-                                int32_t* __restrict__ val) {
+// what the finishing kernel adds for every block: one candidate per (window, slot a <= slot b) of a class;
+// its sort key is the block of the two cameras (nb: none - a slot without a camera, or a pair without a
+// shared point).  `at`: first candidate of this class in the list (class 0 first).
+__global__ void k_fb_candidates(const int32_t* __restrict__ key_cam, int32_t n_keys, int lanes, int cls, int64_t at,
+                                const int32_t* __restrict__ seen, const int32_t* __restrict__ blk_of, int32_t m, int32_t nb,
+                                uint32_t* __restrict__ key, int32_t* __restrict__ val) {
+  const int pairs = lanes * (lanes + 1) / 2;
   const int64_t t = (int64_t)blockIdx.x * kT + threadIdx.x;
-  if (t >= (int64_t)n_keys * 36) return;
-  const int32_t q = (int32_t)(t / 36);
-  int pr = (int)(t - (int64_t)q * 36), a = 0;
-  while (pr >= 8 - a) {  // pairs (a, b >= a) in the order a = 0: 8 of them, a = 1: 7, ...
-    pr -= 8 - a;
+  if (t >= (int64_t)n_keys * pairs) return;
+  const int32_t q = (int32_t)(t / pairs);
+  int pr = (int)(t - (int64_t)q * pairs), a = 0;
+  while (pr >= lanes - a) {  // pairs (a, b >= a) in the order a = 0: `lanes` of them, a = 1: lanes - 1, ...
+    pr -= lanes - a;
     ++a;
   }
   const int b = a + pr;
-  const int32_t ca = key_cam[(int64_t)8 * q + a], cb = key_cam[(int64_t)8 * q + b];
+  const int32_t ca = key_cam[(int64_t)lanes * q + a], cb = key_cam[(int64_t)lanes * q + b];
   int32_t id = nb;
   if (ca >= 0 && cb >= 0 && seen[(int64_t)ca * m + cb]) id = blk_of[(int64_t)ca * m + cb];
-  key[t] = (uint32_t)id;
-  val[t] = (q << 6) | (a << 3) | b;
+  key[at + t] = (uint32_t)id;
+  val[at + t] = fz_fb_pack(cls, q, a, b);
 }
 
 // first position of every value 0 .. n_values in a sorted key list (lower bound)
@@ -744,7 +744,6 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
   // ---- near points of the fused point-major assembly, far points (same rules as the host builder) ----
   // (a list that names a (camera, point) pair twice - accepted only without checks - stays on the
   // camera-pair path, which adds both; the slot table of the fused path has room for one)
-  int slots = 0;
   if (!(flags & kPlanNoFused) && !h[ST_NONUNIQUE]) {
     unsigned long long* hist;
     SFMBA_HIP(scratch.get(&hist, 18));
@@ -758,109 +757,119 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
       obs_by_k[v] = (int64_t)hh[v];
       obs_by_span[v] = (int64_t)hh[9 + v];
     }
-    slots = fz_choose_slots(obs_by_k, obs_by_span);
-  }
-  if (slots > 0) {
-    // windows and sort keys; candidates sorted by key (stable: ascending point id inside a key)
-    int32_t *desc, *ident, *sorted_pt;
-    uint64_t *wkey, *wkey_sorted;
-    SFMBA_HIP(scratch.get(&desc, (int64_t)8 * n));
-    SFMBA_HIP(scratch.get(&ident, n));
-    SFMBA_HIP(scratch.get(&sorted_pt, n));
-    SFMBA_HIP(scratch.get(&wkey, n));
-    SFMBA_HIP(scratch.get(&wkey_sorted, n));
-    k_fz_desc<<<blocks_for(n), kT, 0, st>>>(p->d_pt_ptr, p->d_slot_cam, n, slots, m, desc, wkey, ident, d_stats + ST_N_CAND);
-    SFMBA_TRY(sort_pairs(wkey, wkey_sorted, ident, sorted_pt, n, 34, scratch, st));
-    SFMBA_TRY(read_stats());
-    const int32_t n_cand = h[ST_N_CAND];
-    // windows of the sorted candidates, the ones long enough to keep, positions of the near points
-    int32_t *flag, *wid_excl, *wstart, *keepf, *wkeep, *newpos, *newwid;
-    SFMBA_HIP(scratch.get(&flag, n_cand + 1));
-    SFMBA_HIP(scratch.get(&wid_excl, n_cand + 1));
-    k_fz_win_flags<<<blocks_for(n_cand + 1), kT, 0, st>>>(sorted_pt, desc, n_cand, flag);
-    SFMBA_TRY(scan_exclusive(flag, wid_excl, n_cand + 1, scratch, st));
-    int32_t n_win = 0;
-    SFMBA_HIP(hipMemcpyAsync(&n_win, wid_excl + n_cand, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    SFMBA_HIP(hipStreamSynchronize(st));
-    SFMBA_HIP(scratch.get(&wstart, n_win + 1));
-    SFMBA_HIP(scratch.get(&keepf, n_cand + 1));
-    SFMBA_HIP(scratch.get(&newpos, n_cand + 1));
-    SFMBA_HIP(scratch.get(&wkeep, n_win + 1));
-    SFMBA_HIP(scratch.get(&newwid, n_win + 1));
-    k_fz_win_starts<<<blocks_for(n_cand + 1), kT, 0, st>>>(flag, wid_excl, n_cand, wstart);
-    k_fz_keep<<<blocks_for(std::max(n_cand, n_win) + 1), kT, 0, st>>>(flag, wid_excl, wstart, n_cand, n_win, keepf, wkeep);
-    SFMBA_TRY(scan_exclusive(keepf, newpos, n_cand + 1, scratch, st));
-    SFMBA_TRY(scan_exclusive(wkeep, newwid, n_win + 1, scratch, st));
-    int32_t n_near = 0, n_keys = 0;
-    SFMBA_HIP(hipMemcpyAsync(&n_near, newpos + n_cand, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    SFMBA_HIP(hipMemcpyAsync(&n_keys, newwid + n_win, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    SFMBA_HIP(hipStreamSynchronize(st));
-    const int32_t pmax = fz_pmax_for(n_near);
-    int32_t n_runs = 0;
-    int32_t *near_pos, *fz_pt = nullptr, *pos_key = nullptr, *win_start = nullptr, *run_flag = nullptr, *rid = nullptr,
-            *key_cam = nullptr;
-    SFMBA_HIP(scratch.get(&near_pos, n));
-    SFMBA_HIP(hipMemsetAsync(near_pos, 0xFF, sizeof(int32_t) * (size_t)std::max(n, 1), st));
-    if (n_near > 0) {
+    int32_t* taken;  // class in which the point is near, -1: none (yet)
+    SFMBA_HIP(scratch.get(&taken, n));
+    SFMBA_HIP(hipMemsetAsync(taken, 0xFF, sizeof(int32_t) * (size_t)std::max(n, 1), st));
+    for (int c = 0; c < kFzClasses; ++c) {
+      const int slots = c == 0 ? fz_choose_slots(obs_by_k, obs_by_span) : 16;
+      if (slots <= 0) continue;
+      const int lanes = fz_lanes(slots);
+      // windows and sort keys; candidates sorted by key (stable: ascending point id inside a key)
+      int32_t *desc, *ident, *sorted_pt;
+      uint64_t *wkey, *wkey_sorted;
+      SFMBA_HIP(scratch.get(&desc, (int64_t)lanes * n));
+      SFMBA_HIP(scratch.get(&ident, n));
+      SFMBA_HIP(scratch.get(&sorted_pt, n));
+      SFMBA_HIP(scratch.get(&wkey, n));
+      SFMBA_HIP(scratch.get(&wkey_sorted, n));
+      SFMBA_HIP(hipMemsetAsync(d_stats + ST_N_CAND, 0, sizeof(int32_t), st));
+      k_fz_desc<<<blocks_for(n), kT, 0, st>>>(p->d_pt_ptr, p->d_slot_cam, taken, n, slots, lanes, m, desc, wkey, ident,
+                                             d_stats + ST_N_CAND);
+      SFMBA_TRY(sort_pairs(wkey, wkey_sorted, ident, sorted_pt, n, 34, scratch, st));
+      SFMBA_TRY(read_stats());
+      const int32_t n_cand = h[ST_N_CAND];
+      // windows of the sorted candidates, the ones long enough to keep, positions of the near points
+      int32_t *flag, *wid_excl, *wstart, *keepf, *wkeep, *newpos, *newwid;
+      SFMBA_HIP(scratch.get(&flag, n_cand + 1));
+      SFMBA_HIP(scratch.get(&wid_excl, n_cand + 1));
+      k_fz_win_flags<<<blocks_for(n_cand + 1), kT, 0, st>>>(sorted_pt, desc, lanes, n_cand, flag);
+      SFMBA_TRY(scan_exclusive(flag, wid_excl, n_cand + 1, scratch, st));
+      int32_t n_win = 0;
+      SFMBA_HIP(hipMemcpyAsync(&n_win, wid_excl + n_cand, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      SFMBA_HIP(hipStreamSynchronize(st));
+      SFMBA_HIP(scratch.get(&wstart, n_win + 1));
+      SFMBA_HIP(scratch.get(&keepf, n_cand + 1));
+      SFMBA_HIP(scratch.get(&newpos, n_cand + 1));
+      SFMBA_HIP(scratch.get(&wkeep, n_win + 1));
+      SFMBA_HIP(scratch.get(&newwid, n_win + 1));
+      k_fz_win_starts<<<blocks_for(n_cand + 1), kT, 0, st>>>(flag, wid_excl, n_cand, wstart);
+      k_fz_keep<<<blocks_for(std::max(n_cand, n_win) + 1), kT, 0, st>>>(flag, wid_excl, wstart, n_cand, n_win,
+                                                                       fz_min_window_points(c), keepf, wkeep);
+      SFMBA_TRY(scan_exclusive(keepf, newpos, n_cand + 1, scratch, st));
+      SFMBA_TRY(scan_exclusive(wkeep, newwid, n_win + 1, scratch, st));
+      int32_t n_near = 0, n_keys = 0;
+      SFMBA_HIP(hipMemcpyAsync(&n_near, newpos + n_cand, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      SFMBA_HIP(hipMemcpyAsync(&n_keys, newwid + n_win, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      SFMBA_HIP(hipStreamSynchronize(st));
+      if (n_near <= 0) continue;
+      const int32_t pmax = fz_pmax_for(n_near);
+      int32_t n_runs = 0;
+      int32_t *near_pos, *fz_pt, *pos_key, *win_start, *run_flag, *rid, *key_cam;
+      SFMBA_HIP(scratch.get(&near_pos, n));
+      SFMBA_HIP(hipMemsetAsync(near_pos, 0xFF, sizeof(int32_t) * (size_t)std::max(n, 1), st));
       SFMBA_HIP(scratch.get(&fz_pt, n_near));
       SFMBA_HIP(scratch.get(&pos_key, n_near));
       SFMBA_HIP(scratch.get(&win_start, n_near));
       SFMBA_HIP(scratch.get(&run_flag, n_near + 1));
       SFMBA_HIP(scratch.get(&rid, n_near + 1));
-      SFMBA_HIP(scratch.get(&key_cam, (int64_t)8 * n_keys));
-      k_fz_place<<<blocks_for(n_cand + 1), kT, 0, st>>>(sorted_pt, flag, wid_excl, keepf, newpos, newwid, desc, n_cand, n_near,
-                                                       pmax, fz_pt, near_pos, pos_key, win_start, run_flag, key_cam);
+      SFMBA_HIP(scratch.get(&key_cam, (int64_t)lanes * n_keys));
+      k_fz_place<<<blocks_for(n_cand + 1), kT, 0, st>>>(sorted_pt, flag, wid_excl, keepf, newpos, newwid, desc, lanes, n_cand,
+                                                       n_near, pmax, fz_pt, near_pos, pos_key, win_start, run_flag, key_cam);
       SFMBA_TRY(scan_exclusive(run_flag, rid, n_near + 1, scratch, st));
       SFMBA_HIP(hipMemcpyAsync(&n_runs, rid + n_near, sizeof(int32_t), hipMemcpyDeviceToHost, st));
       SFMBA_HIP(hipStreamSynchronize(st));
+      if (!fz_worthwhile(c, n, n_near, n_runs)) continue;
+      FzClass& f = p->fz[c];
+      f.slots = slots;
+      f.lanes = lanes;
+      f.pmax = pmax;
+      f.n_near = n_near;
+      f.n_runs = n_runs;
+      f.n_keys = n_keys;
+      f.n_ranges = (n_near + pmax - 1) / pmax;
+      p->n_runs += n_runs;
+      SFMBA_TRY(keep(&f.d_pt, n_near, &bytes));
+      SFMBA_HIP(hipMemcpyAsync(f.d_pt, fz_pt, sizeof(int32_t) * (size_t)n_near, hipMemcpyDeviceToDevice, st));
+      SFMBA_TRY(keep(&f.d_key_cam, (int64_t)lanes * n_keys, &bytes));
+      SFMBA_HIP(hipMemcpyAsync(f.d_key_cam, key_cam, sizeof(int32_t) * lanes * (size_t)n_keys, hipMemcpyDeviceToDevice, st));
+      SFMBA_TRY(keep(&f.d_run_pt0, n_runs + 1, &bytes));
+      SFMBA_TRY(keep(&f.d_run_key, n_runs, &bytes));
+      SFMBA_TRY(keep(&f.d_run_cam, (int64_t)lanes * n_runs, &bytes));
+      SFMBA_TRY(keep(&f.d_key_run, n_keys + 1, &bytes));
+      SFMBA_TRY(keep(&f.d_rng_run, f.n_ranges + 1, &bytes));
+      k_fz_runs<<<blocks_for(n_near + 1), kT, 0, st>>>(run_flag, rid, win_start, pos_key, f.d_key_cam, lanes, n_near, n_keys,
+                                                      pmax, f.d_run_pt0, f.d_run_key, f.d_run_cam, f.d_key_run, f.d_rng_run);
+      SFMBA_TRY(keep(&f.d_slot_obs, (int64_t)n_near * lanes, &bytes));
+      SFMBA_HIP(hipMemsetAsync(f.d_slot_obs, 0xFF, sizeof(int32_t) * (size_t)n_near * lanes, st));
+      k_slot_obs_fill<<<blocks_for(N), kT, 0, st>>>(slot_pt, p->d_slot_cam, p->d_perm, near_pos, desc, lanes, c, N, f.d_slot_obs,
+                                                   taken);
+      {
+        // steps, most runs of a range: from the run boundaries, on the host
+        std::vector<int32_t> rp((size_t)n_runs + 1), rr((size_t)f.n_ranges + 1);
+        SFMBA_HIP(hipMemcpyAsync(rp.data(), f.d_run_pt0, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, st));
+        SFMBA_HIP(hipMemcpyAsync(rr.data(), f.d_rng_run, sizeof(int32_t) * rr.size(), hipMemcpyDeviceToHost, st));
+        SFMBA_HIP(hipStreamSynchronize(st));
+        const int pps = 64 / lanes;
+        for (int32_t r = 0; r < n_runs; ++r) f.n_steps += (rp[(size_t)r + 1] - rp[(size_t)r] + pps - 1) / pps;
+        for (int32_t g = 0; g < f.n_ranges; ++g) f.max_range_runs = std::max(f.max_range_runs, rr[(size_t)g + 1] - rr[(size_t)g]);
+      }
     }
-    // far points and their observations (before the decision: it needs their number)
-    int32_t *pflag, *pnum, *oflag, *onum;
-    SFMBA_HIP(scratch.get(&pflag, n + 1));
-    SFMBA_HIP(scratch.get(&pnum, n + 1));
-    SFMBA_HIP(scratch.get(&oflag, N + 1));
-    SFMBA_HIP(scratch.get(&onum, N + 1));
-    k_far_flags<<<blocks_for(std::max<int64_t>(n, N) + 1), kT, 0, st>>>(near_pos, pt, n, N, pflag, oflag);
-    SFMBA_TRY(scan_exclusive(pflag, pnum, n + 1, scratch, st));
-    SFMBA_TRY(scan_exclusive(oflag, onum, N + 1, scratch, st));
-    int32_t n_far = 0, n_far_obs = 0;
-    SFMBA_HIP(hipMemcpyAsync(&n_far, pnum + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    SFMBA_HIP(hipMemcpyAsync(&n_far_obs, onum + N, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    SFMBA_HIP(hipStreamSynchronize(st));
-    // (points without observations - allowed on plans built with size hints - go with the far points)
-    if (fz_worthwhile(n, n_near, n_runs)) {
-      p->fz_slots = slots;
-      p->fz_pmax = pmax;
-      p->n_near = n_near;
-      p->n_runs = n_runs;
-      p->n_keys = n_keys;
-      p->n_ranges = (n_near + pmax - 1) / pmax;
+    if (p->n_runs > 0) {
+      // far points (those no class took) and their observations
+      int32_t *pflag, *pnum, *oflag, *onum;
+      SFMBA_HIP(scratch.get(&pflag, n + 1));
+      SFMBA_HIP(scratch.get(&pnum, n + 1));
+      SFMBA_HIP(scratch.get(&oflag, N + 1));
+      SFMBA_HIP(scratch.get(&onum, N + 1));
+      k_far_flags<<<blocks_for(std::max<int64_t>(n, N) + 1), kT, 0, st>>>(taken, pt, n, N, pflag, oflag);
+      SFMBA_TRY(scan_exclusive(pflag, pnum, n + 1, scratch, st));
+      SFMBA_TRY(scan_exclusive(oflag, onum, N + 1, scratch, st));
+      int32_t n_far = 0, n_far_obs = 0;
+      SFMBA_HIP(hipMemcpyAsync(&n_far, pnum + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      SFMBA_HIP(hipMemcpyAsync(&n_far_obs, onum + N, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      SFMBA_HIP(hipStreamSynchronize(st));
       p->n_far = n_far;
       p->n_far_obs = n_far_obs;
-      SFMBA_TRY(keep(&p->d_fz_pt, n_near, &bytes));
-      SFMBA_HIP(hipMemcpyAsync(p->d_fz_pt, fz_pt, sizeof(int32_t) * (size_t)n_near, hipMemcpyDeviceToDevice, st));
-      SFMBA_TRY(keep(&p->d_key_cam, (int64_t)8 * n_keys, &bytes));
-      SFMBA_HIP(hipMemcpyAsync(p->d_key_cam, key_cam, sizeof(int32_t) * 8 * (size_t)n_keys, hipMemcpyDeviceToDevice, st));
-      SFMBA_TRY(keep(&p->d_run_pt0, n_runs + 1, &bytes));
-      SFMBA_TRY(keep(&p->d_run_key, n_runs, &bytes));
-      SFMBA_TRY(keep(&p->d_run_cam, (int64_t)8 * n_runs, &bytes));
-      SFMBA_TRY(keep(&p->d_key_run, n_keys + 1, &bytes));
-      SFMBA_TRY(keep(&p->d_rng_run, p->n_ranges + 1, &bytes));
-      k_fz_runs<<<blocks_for(n_near + 1), kT, 0, st>>>(run_flag, rid, win_start, pos_key, p->d_key_cam, n_near, n_keys, pmax,
-                                                      p->d_run_pt0, p->d_run_key, p->d_run_cam, p->d_key_run, p->d_rng_run);
-      SFMBA_TRY(keep(&p->d_slot_obs, (int64_t)n_near * kFzLanesPerPoint, &bytes));
-      SFMBA_HIP(hipMemsetAsync(p->d_slot_obs, 0xFF, sizeof(int32_t) * (size_t)n_near * kFzLanesPerPoint, st));
-      k_slot_obs_fill<<<blocks_for(N), kT, 0, st>>>(slot_pt, p->d_slot_cam, p->d_perm, near_pos, desc, N, p->d_slot_obs);
-      {
-        // steps of 8 points, most runs of a range: from the run boundaries, on the host
-        std::vector<int32_t> rp((size_t)n_runs + 1), rr((size_t)p->n_ranges + 1);
-        SFMBA_HIP(hipMemcpyAsync(rp.data(), p->d_run_pt0, sizeof(int32_t) * rp.size(), hipMemcpyDeviceToHost, st));
-        SFMBA_HIP(hipMemcpyAsync(rr.data(), p->d_rng_run, sizeof(int32_t) * rr.size(), hipMemcpyDeviceToHost, st));
-        SFMBA_HIP(hipStreamSynchronize(st));
-        for (int32_t r = 0; r < n_runs; ++r) p->n_steps += (rp[(size_t)r + 1] - rp[(size_t)r] + 7) / 8;
-        for (int32_t g = 0; g < p->n_ranges; ++g)
-          p->fz_max_range_runs = std::max(p->fz_max_range_runs, rr[(size_t)g + 1] - rr[(size_t)g]);
-      }
       SFMBA_TRY(keep(&p->d_far_pt, n_far, &bytes));
       SFMBA_TRY(keep(&p->d_far_obs, n_far_obs, &bytes));
       SFMBA_TRY(keep(&p->d_far_cam, n_far_obs, &bytes));
@@ -873,15 +882,25 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
         if (!p->far) return SFM_BA_EINVAL;
         SFMBA_TRY(build(p->d_far_cam, p->d_far_lpt, n_far_obs, m, n_far, 0, kPlanNoFused | kPlanForceParts, st, p->far));
       }
-      // entries of the finishing kernel: candidates sorted by block (stable: ascending window inside a block)
-      const int64_t n_fc = (int64_t)n_keys * 36;
+      // entries of the finishing kernel: candidates (class 0 first) sorted by block (stable: ascending
+      // window inside a block and class)
+      int64_t n_fc = 0, at[kFzClasses];
+      for (int c = 0; c < kFzClasses; ++c) {
+        at[c] = n_fc;
+        n_fc += (int64_t)p->fz[c].n_keys * (p->fz[c].lanes * (p->fz[c].lanes + 1) / 2);
+      }
       uint32_t *fkey, *fkey_sorted;
       int32_t *fval, *fval_sorted;
       SFMBA_HIP(scratch.get(&fkey, n_fc));
       SFMBA_HIP(scratch.get(&fkey_sorted, n_fc));
       SFMBA_HIP(scratch.get(&fval, n_fc));
       SFMBA_HIP(scratch.get(&fval_sorted, n_fc));
-      k_fb_candidates<<<blocks_for(n_fc), kT, 0, st>>>(p->d_key_cam, n_keys, seen, blk_of, m, nb, fkey, fval);
+      for (int c = 0; c < kFzClasses; ++c) {
+        const FzClass& f = p->fz[c];
+        if (f.n_keys <= 0) continue;
+        k_fb_candidates<<<blocks_for((int64_t)f.n_keys * (f.lanes * (f.lanes + 1) / 2)), kT, 0, st>>>(
+            f.d_key_cam, f.n_keys, f.lanes, c, at[c], seen, blk_of, m, nb, fkey, fval);
+      }
       SFMBA_TRY(sort_pairs(fkey, fkey_sorted, fval, fval_sorted, n_fc, bits_for((int64_t)nb + 1), scratch, st));
       SFMBA_TRY(keep(&p->d_fb_ptr, nb + 1, &bytes));
       k_lower_bounds<<<blocks_for(nb + 1), kT, 0, st>>>(fkey_sorted, n_fc, nb, p->d_fb_ptr);
@@ -893,10 +912,11 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
       SFMBA_HIP(hipMemcpyAsync(p->d_fb_ent, fval_sorted, sizeof(int32_t) * (size_t)n_fb, hipMemcpyDeviceToDevice, st));
       SFMBA_TRY(keep(&p->d_fb_far_part, nb, &bytes));
       SFMBA_TRY(keep(&p->d_fb_far_cnt, nb, &bytes));
-      const sfm_ba_plan* f = p->far;
-      k_fb_far<<<blocks_for(nb), kT, 0, st>>>(p->d_blk_j, p->d_blk_k, nb, f ? f->d_blk_j : nullptr, f ? f->d_blk_k : nullptr,
-                                             f ? f->d_mb_part : nullptr, f ? f->d_mb_cnt : nullptr, f ? f->n_blocks : 0, m,
-                                             p->d_fb_far_part, p->d_fb_far_cnt);
+      const sfm_ba_plan* fp = p->far;
+      k_fb_far<<<blocks_for(nb), kT, 0, st>>>(p->d_blk_j, p->d_blk_k, nb, fp ? fp->d_blk_j : nullptr,
+                                             fp ? fp->d_blk_k : nullptr, fp ? fp->d_mb_part : nullptr,
+                                             fp ? fp->d_mb_cnt : nullptr, fp ? fp->n_blocks : 0, m, p->d_fb_far_part,
+                                             p->d_fb_far_cnt);
     }
   }
   SFMBA_HIP(hipGetLastError());

@@ -48,7 +48,8 @@ class Plan:
               "mb_blk", "mb_part", "mb_cnt", "run_pt0", "run_key", "slot_obs", "key_cam", "key_run", "rng_run", "fz_pt",
               "run_cam", "fb_ptr", "fb_ent", "fb_far_part", "fb_far_cnt", "far_pt", "far_obs", "far_cam", "far_lpt",
               "far_gpt")
-    # the arrays of the fused assembly and of the near / far split
+    # the arrays of the fused assembly (21..28: one set per class of near points) and of the near / far split
+    CLASS_FIELDS = FIELDS[21:29]
     FUSED_FIELDS = FIELDS[21:]
 
     def __init__(self, cam_idx, pt_idx, n_cams_hint=0, n_pts_hint=0, check=True, where="device", _borrowed=None):
@@ -96,11 +97,20 @@ class Plan:
          self.n_items, self.device_bytes) = [int(v) for v in sizes]
         self.workspace_bytes = int(lib.sfm_ba_plan_workspace_bytes(handle))
         self.half_bandwidth = int(lib.sfm_ba_plan_half_bandwidth(handle))
-        info = (C.c_int32 * 8)()
+        info = (C.c_int32 * 16)()
         _lib.check(lib.sfm_ba_plan_fused_info(handle, info))
-        # fused point-major assembly over the near points (0 runs: the plan has no such path)
-        (self.fused, self.fused_slots, self.n_near, self.fused_pmax, self.n_runs, self.n_keys, self.n_steps,
-         self.n_ranges) = [int(v) for v in info]
+        # fused point-major assembly over the near points, per class (0: windows of up to 8 cameras,
+        # 1: windows of 16); no runs: the plan has no such path
+        names = ("on", "slots", "n_near", "pmax", "n_runs", "n_keys", "n_steps", "n_ranges")
+        self.classes = [dict(zip(names, [int(v) for v in info[8 * c: 8 * c + 8]])) for c in range(2)]
+        c0 = self.classes[0]
+        self.fused = int(any(c["on"] for c in self.classes))
+        self.fused_slots, self.fused_pmax = c0["slots"], c0["pmax"]
+        self.n_near = sum(c["n_near"] for c in self.classes)
+        self.n_runs = sum(c["n_runs"] for c in self.classes)
+        self.n_keys = sum(c["n_keys"] for c in self.classes)
+        self.n_steps = sum(c["n_steps"] for c in self.classes)
+        self.n_ranges = sum(c["n_ranges"] for c in self.classes)
         far = lib.sfm_ba_plan_far(handle)
         # far points: a plan of their own (camera-pair kernels), None when every point is near
         self.far = Plan(None, None, _borrowed=(self, C.c_void_p(far))) if far else None
@@ -111,10 +121,13 @@ class Plan:
         """Turn the fused point-major assembly of this plan on or off (on by default where runs exist)."""
         _lib.check(self._lib.sfm_ba_plan_set_fused(self.handle, int(bool(enable))))
         self.fused = int(bool(enable) and self.n_runs > 0)
+        for c in self.classes:
+            c["on"] = int(bool(enable) and c["n_runs"] > 0)
 
-    def read(self, field):
-        """One index array of the plan as a host array (``entries``: uint32 (n, 2))."""
-        idx = self.FIELDS.index(field)
+    def read(self, field, cls=0):
+        """One index array of the plan as a host array (``entries``: uint32 (n, 2)).  ``cls``: class of
+        near points (0 / 1) for the arrays of the fused assembly that exist per class."""
+        idx = self.FIELDS.index(field) + (100 if cls else 0)
         nbytes = C.c_int64()
         _lib.check(self._lib.sfm_ba_plan_read(self.handle, idx, None, 0, C.byref(nbytes)))
         out = np.empty(nbytes.value // 4, dtype=np.uint32 if field == "entries" else np.int32)

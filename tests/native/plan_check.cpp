@@ -15,6 +15,7 @@
 #include <cstring>
 #include <random>
 #include <set>
+#include <tuple>
 
 static hipError_t host_alloc(void** p, size_t sz) {
   *p = malloc(sz);
@@ -141,92 +142,107 @@ int main(int argc, char** argv) {
   sfm_ba_plan* p = nullptr;
   REQUIRE(sfm_ba_plan_create(cam.data(), pt.data(), N, m, n, 0, &p) == SFM_BA_OK);
   if (check_pairs(p, cam, pt)) return 1;
-  // near points of the fused assembly: their positions are tiled by runs, every observation of a near
-  // point sits at the slot of its camera in its run's window, every other slot is empty
+  // near points of the fused assembly, per class: their positions are tiled by runs, every observation of
+  // a near point sits at the slot of its camera in its run's window, every other slot is empty
   int64_t near_obs = 0;
+  int n_near_all = 0;
   if (p->n_runs > 0) {
-    REQUIRE(p->fz_slots >= 4 && p->fz_slots <= 8 && p->fz_pmax >= 8);
-    REQUIRE(p->n_near > 0 && p->n_near <= n);
-    REQUIRE(p->d_run_pt0[0] == 0 && p->d_run_pt0[p->n_runs] == p->n_near);
-    std::vector<int> pos_of((size_t)n, -1);
-    for (int q = 0; q < p->n_near; ++q) {
-      const int i = p->d_fz_pt[q];
-      REQUIRE(i >= 0 && i < n && pos_of[(size_t)i] < 0);
-      pos_of[(size_t)i] = q;
-    }
+    std::vector<int> cls_of((size_t)n, -1);
     std::vector<int64_t> seen_obs((size_t)N, 0);
-    std::set<std::pair<int, int>> need;  // (block, window) pairs the finishing kernel must find
+    std::set<std::tuple<int, int, int>> need;  // (block, class, window) the finishing kernel must find
     std::vector<int> blk_of((size_t)m * m, -1);
     for (int b = 0; b < p->n_blocks; ++b) blk_of[(size_t)p->d_blk_j[b] * m + p->d_blk_k[b]] = b;
-    int steps = 0;
-    for (int r = 0; r < p->n_runs; ++r) {
-      const int key = p->d_run_key[r];
-      REQUIRE(key >= 0 && key < p->n_keys);
-      REQUIRE(p->d_run_pt0[r + 1] > p->d_run_pt0[r] && p->d_run_pt0[r + 1] - p->d_run_pt0[r] <= p->fz_pmax);
-      REQUIRE(r == 0 || p->d_run_key[r - 1] == key || p->d_run_key[r - 1] == key - 1);
-      steps += (p->d_run_pt0[r + 1] - p->d_run_pt0[r] + 7) / 8;
-      const int32_t* kc = p->d_key_cam + 8 * key;
-      for (int sl = 0; sl < 8; ++sl) {
-        REQUIRE(kc[sl] >= -1 && kc[sl] < m && (sl < p->fz_slots || kc[sl] < 0));
-        const int rc = p->d_run_cam[8 * r + sl];
-        REQUIRE(rc >= 0 && rc < m && (kc[sl] < 0 || rc == kc[sl]));
+    int runs_all = 0;
+    for (int c = 0; c < sfmba::kFzClasses; ++c) {
+      const sfmba::FzClass& f = p->fz[c];
+      if (f.n_runs == 0) {
+        REQUIRE(f.n_near == 0 && f.n_keys == 0);
+        continue;
       }
-      for (int q = p->d_run_pt0[r]; q < p->d_run_pt0[r + 1]; ++q) {
-        int cams_q[8], nq = 0;
-        for (int sl = 0; sl < 8; ++sl) {
-          const int32_t o = p->d_slot_obs[(size_t)q * 8 + sl];
-          if (o < 0) continue;
-          REQUIRE(sl < p->fz_slots && o < N && pt[(size_t)o] == p->d_fz_pt[q] && cam[(size_t)o] == kc[sl]);
-          ++seen_obs[(size_t)o];
-          cams_q[nq++] = kc[sl];
+      runs_all += f.n_runs;
+      n_near_all += f.n_near;
+      const int L = f.lanes, pps = 64 / L;
+      REQUIRE(c == 0 ? (f.slots >= 4 && f.slots <= 8 && L == 8) : (f.slots == 16 && L == 16));
+      REQUIRE(f.pmax >= 8 && f.n_near > 0 && f.n_near <= n);
+      REQUIRE(f.d_run_pt0[0] == 0 && f.d_run_pt0[f.n_runs] == f.n_near);
+      for (int q = 0; q < f.n_near; ++q) {
+        const int i = f.d_pt[q];
+        REQUIRE(i >= 0 && i < n && cls_of[(size_t)i] < 0);
+        cls_of[(size_t)i] = c;
+      }
+      int steps = 0;
+      for (int r = 0; r < f.n_runs; ++r) {
+        const int key = f.d_run_key[r];
+        REQUIRE(key >= 0 && key < f.n_keys);
+        REQUIRE(f.d_run_pt0[r + 1] > f.d_run_pt0[r] && f.d_run_pt0[r + 1] - f.d_run_pt0[r] <= f.pmax);
+        REQUIRE(r == 0 || f.d_run_key[r - 1] == key || f.d_run_key[r - 1] == key - 1);
+        steps += (f.d_run_pt0[r + 1] - f.d_run_pt0[r] + pps - 1) / pps;
+        const int32_t* kc = f.d_key_cam + L * key;
+        for (int sl = 0; sl < L; ++sl) {
+          REQUIRE(kc[sl] >= -1 && kc[sl] < m && (sl < f.slots || kc[sl] < 0));
+          const int rc = f.d_run_cam[L * r + sl];
+          REQUIRE(rc >= 0 && rc < m && (kc[sl] < 0 || rc == kc[sl]));
         }
-        REQUIRE(nq >= 1);
-        for (int a = 0; a < nq; ++a)
-          for (int b = a; b < nq; ++b) {
-            const int lo = std::min(cams_q[a], cams_q[b]), hi = std::max(cams_q[a], cams_q[b]);
-            REQUIRE(blk_of[(size_t)lo * m + hi] >= 0);
-            need.insert({blk_of[(size_t)lo * m + hi], key});
+        for (int q = f.d_run_pt0[r]; q < f.d_run_pt0[r + 1]; ++q) {
+          int cams_q[16], nq = 0;
+          for (int sl = 0; sl < L; ++sl) {
+            const int32_t o = f.d_slot_obs[(size_t)q * L + sl];
+            if (o < 0) continue;
+            REQUIRE(sl < f.slots && o < N && pt[(size_t)o] == f.d_pt[q] && cam[(size_t)o] == kc[sl]);
+            ++seen_obs[(size_t)o];
+            cams_q[nq++] = kc[sl];
           }
+          REQUIRE(nq >= 1);
+          for (int a = 0; a < nq; ++a)
+            for (int b = a; b < nq; ++b) {
+              const int lo = std::min(cams_q[a], cams_q[b]), hi = std::max(cams_q[a], cams_q[b]);
+              REQUIRE(blk_of[(size_t)lo * m + hi] >= 0);
+              need.insert({blk_of[(size_t)lo * m + hi], c, key});
+            }
+        }
+      }
+      REQUIRE(steps == f.n_steps);
+      // ranges of pmax positions own whole runs
+      REQUIRE(f.n_ranges == (f.n_near + f.pmax - 1) / f.pmax);
+      REQUIRE(f.d_rng_run[0] == 0 && f.d_rng_run[f.n_ranges] == f.n_runs);
+      int max_range_runs = 0;
+      for (int g = 0; g < f.n_ranges; ++g) {
+        REQUIRE(f.d_rng_run[g + 1] > f.d_rng_run[g]);
+        REQUIRE(f.d_run_pt0[f.d_rng_run[g]] == g * f.pmax);
+        max_range_runs = std::max(max_range_runs, f.d_rng_run[g + 1] - f.d_rng_run[g]);
+      }
+      REQUIRE(max_range_runs == f.max_range_runs);
+      // the runs of a window are consecutive; windows differ from their neighbours and hold enough points
+      REQUIRE(f.d_key_run[0] == 0 && f.d_key_run[f.n_keys] == f.n_runs);
+      for (int q = 0; q < f.n_keys; ++q) {
+        REQUIRE(f.d_key_run[q + 1] > f.d_key_run[q]);
+        for (int r = f.d_key_run[q]; r < f.d_key_run[q + 1]; ++r) REQUIRE(f.d_run_key[r] == q);
+        REQUIRE(f.d_run_pt0[f.d_key_run[q + 1]] - f.d_run_pt0[f.d_key_run[q]] >= sfmba::fz_min_window_points(c));
+        if (q > 0) REQUIRE(memcmp(f.d_key_cam + L * q, f.d_key_cam + L * (q - 1), 4 * L) != 0);
       }
     }
-    REQUIRE(steps == p->n_steps);
+    REQUIRE(runs_all == p->n_runs);
+    std::vector<int> pos_of(cls_of);  // >= 0: near
     for (int64_t o = 0; o < N; ++o) {
       REQUIRE(seen_obs[(size_t)o] == (pos_of[(size_t)pt[(size_t)o]] >= 0 ? 1 : 0));
       near_obs += seen_obs[(size_t)o];
     }
-    // ranges of pmax positions own whole runs
-    REQUIRE(p->n_ranges == (p->n_near + p->fz_pmax - 1) / p->fz_pmax);
-    REQUIRE(p->d_rng_run[0] == 0 && p->d_rng_run[p->n_ranges] == p->n_runs);
-    int max_range_runs = 0;
-    for (int g = 0; g < p->n_ranges; ++g) {
-      REQUIRE(p->d_rng_run[g + 1] > p->d_rng_run[g]);
-      REQUIRE(p->d_run_pt0[p->d_rng_run[g]] == g * p->fz_pmax);
-      max_range_runs = std::max(max_range_runs, p->d_rng_run[g + 1] - p->d_rng_run[g]);
-    }
-    REQUIRE(max_range_runs == p->fz_max_range_runs);
-    // the runs of a window are consecutive; windows differ from their neighbours and hold enough points
-    REQUIRE(p->d_key_run[0] == 0 && p->d_key_run[p->n_keys] == p->n_runs);
-    for (int q = 0; q < p->n_keys; ++q) {
-      REQUIRE(p->d_key_run[q + 1] > p->d_key_run[q]);
-      for (int r = p->d_key_run[q]; r < p->d_key_run[q + 1]; ++r) REQUIRE(p->d_run_key[r] == q);
-      REQUIRE(p->d_run_pt0[p->d_key_run[q + 1]] - p->d_run_pt0[p->d_key_run[q]] >= sfmba::kFzMinWindowPoints);
-      if (q > 0) REQUIRE(memcmp(p->d_key_cam + 8 * q, p->d_key_cam + 8 * (q - 1), 32) != 0);
-    }
-    // entries of the finishing kernel: per block ascending windows, the right cameras at the slots,
-    // and every (block, window) that holds a point's pair of cameras is there
+    // entries of the finishing kernel: per block class 0 before class 1, ascending windows, the right
+    // cameras at the slots, and every (block, class, window) that holds a point's pair of cameras is there
     REQUIRE(p->d_fb_ptr[0] == 0 && p->d_fb_ptr[p->n_blocks] == p->n_fb);
     for (int b = 0; b < p->n_blocks; ++b) {
       for (int e = p->d_fb_ptr[b]; e < p->d_fb_ptr[b + 1]; ++e) {
-        const int ent = p->d_fb_ent[e], key = ent >> 6, sj = (ent >> 3) & 7, sk = ent & 7;
-        REQUIRE(key >= 0 && key < p->n_keys);
-        REQUIRE(p->d_key_cam[8 * key + sj] == p->d_blk_j[b] && p->d_key_cam[8 * key + sk] == p->d_blk_k[b]);
-        REQUIRE(e == p->d_fb_ptr[b] || (p->d_fb_ent[e - 1] >> 6) < key);
-        need.erase({b, key});
+        const int ent = p->d_fb_ent[e], c = (ent >> 30) & 1, key = (ent >> 8) & 0x3FFFFF, sj = (ent >> 4) & 15, sk = ent & 15;
+        const sfmba::FzClass& f = p->fz[c];
+        REQUIRE(key >= 0 && key < f.n_keys && sj < f.lanes && sk < f.lanes);
+        REQUIRE(f.d_key_cam[f.lanes * key + sj] == p->d_blk_j[b] && f.d_key_cam[f.lanes * key + sk] == p->d_blk_k[b]);
+        REQUIRE(e == p->d_fb_ptr[b] || (p->d_fb_ent[e - 1] >> 8) < (ent >> 8));
+        need.erase({b, c, key});
       }
     }
     REQUIRE(need.empty());
     // far points: the rest, ascending, with their observations in the caller's relative order
-    REQUIRE(p->n_far == n - p->n_near);
+    REQUIRE(p->n_far == n - n_near_all);
     for (int q = 0; q < p->n_far; ++q) {
       REQUIRE(pos_of[(size_t)p->d_far_pt[q]] < 0);
       REQUIRE(q == 0 || p->d_far_pt[q - 1] < p->d_far_pt[q]);
@@ -237,6 +253,7 @@ int main(int argc, char** argv) {
       const int32_t o = p->d_far_obs[i];
       REQUIRE(o >= 0 && o < N && (i == 0 || p->d_far_obs[i - 1] < o));
       REQUIRE(p->d_far_cam[i] == cam[(size_t)o] && p->d_far_pt[p->d_far_lpt[i]] == pt[(size_t)o]);
+      REQUIRE(p->d_far_gpt[i] == pt[(size_t)o]);
       fcam.push_back(p->d_far_cam[i]);
       fpt.push_back(p->d_far_lpt[i]);
     }
@@ -256,9 +273,10 @@ int main(int argc, char** argv) {
     REQUIRE(p->ws_total >= p->ws_far + (p->far ? p->far->ws_total : 0));
   }
   if (argc > 6) REQUIRE((p->n_runs > 0) == (atoi(argv[6]) != 0));
-  if (argc > 7) REQUIRE(100.0 * p->n_near >= (double)atoi(argv[7]) * n);
-  printf("ok runs=%d windows=%d slots=%d pmax=%d near=%d (%.1f%% of the observations) far=%d ", p->n_runs, p->n_keys,
-         p->fz_slots, p->fz_pmax, p->n_near, 100.0 * (double)near_obs / (double)N, p->n_far);
+  if (argc > 7) REQUIRE(100.0 * n_near_all >= (double)atoi(argv[7]) * n);
+  printf("ok runs=%d windows=%d+%d slots=%d+%d near=%d+%d (%.1f%% of the observations) far=%d ", p->n_runs, p->fz[0].n_keys,
+         p->fz[1].n_keys, p->fz[0].slots, p->fz[1].slots, p->fz[0].n_near, p->fz[1].n_near, 100.0 * (double)near_obs / (double)N,
+         p->n_far);
   printf("m=%d n=%d N=%lld blocks=%d entries=%lld items=%d parts=%d half_bandwidth=%d\n", m, n, (long long)N,
          p->n_blocks, (long long)p->n_entries, p->n_pair_items, p->n_parts, sfm_ba_plan_half_bandwidth(p));
   sfm_ba_plan_destroy(p);

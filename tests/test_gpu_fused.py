@@ -40,7 +40,7 @@ def test_fused_matches_pair_path(m, n, k, slots):
     host = Plan(p.cam_idx, p.pt_idx, where="host")
     dev = Plan(p.cam_idx, p.pt_idx, where="device")
     assert host.fused == dev.fused == 1
-    assert dev.fused_slots == slots and dev.n_near == n and dev.far is None
+    assert dev.fused_slots == slots and dev.classes[0]["n_near"] == n and dev.far is None
     for f in Plan.FUSED_FIELDS:
         a, b = host.read(f), dev.read(f)
         assert a.shape == b.shape and np.array_equal(a, b), f

@@ -64,9 +64,11 @@ def _plans_equal(a, b):
     for f in Plan.FIELDS:
         x, y = a.read(f), b.read(f)
         assert x.shape == y.shape and np.array_equal(x, y), f
+    for f in Plan.CLASS_FIELDS:
+        x, y = a.read(f, cls=1), b.read(f, cls=1)
+        assert x.shape == y.shape and np.array_equal(x, y), (f, "class 1")
     assert a.workspace_bytes == b.workspace_bytes
-    assert (a.fused, a.fused_slots, a.n_near, a.fused_pmax, a.n_runs, a.n_keys, a.n_steps, a.n_ranges) == \
-           (b.fused, b.fused_slots, b.n_near, b.fused_pmax, b.n_runs, b.n_keys, b.n_steps, b.n_ranges)
+    assert a.classes == b.classes
     assert (a.far is None) == (b.far is None)
     if a.far is not None:
         _plans_equal(a.far, b.far)
@@ -146,7 +148,7 @@ def test_shuffled_point_ids(m, n, k):
     host = Plan(p.cam_idx, p.pt_idx, where="host")
     dev = Plan(p.cam_idx, p.pt_idx, where="device")
     _plans_equal(host, dev)
-    assert dev.fused == 1 and dev.n_near == n and dev.far is None
+    assert dev.fused == 1 and dev.classes[0]["n_near"] == n and dev.far is None
     # every observation sits once in the table, at the slot of its camera in its run's window
     so = dev.read("slot_obs").reshape(-1, 8)
     key_of_pos = np.repeat(dev.read("run_key"), np.diff(dev.read("run_pt0")))
@@ -158,27 +160,62 @@ def test_shuffled_point_ids(m, n, k):
     _compare_paths(p, expect_far=False)
 
 
-@pytest.mark.parametrize("m,n,seed,where", [(60, 8000, 1, "device"), (60, 8000, 1, "host"), (90, 30000, 2, "device")])
-def test_near_and_far_points_in_one_plan(m, n, seed, where):
+@pytest.mark.parametrize("m,n,seed,where,long_every,expect_wide", [
+    (60, 8000, 1, "device", 20, False), (60, 8000, 1, "host", 20, False), (90, 30000, 2, "device", 20, False),
+    (40, 30000, 3, "device", 4, True)])
+def test_near_and_far_points_in_one_plan(m, n, seed, where, long_every, expect_wide):
     from sfm_amd.device import Plan
 
-    p, kinds = mixed_problem(m, n, seed)
+    p, kinds = mixed_problem(m, n, seed, long_every=long_every)
     host = Plan(p.cam_idx, p.pt_idx, where="host")
     dev = Plan(p.cam_idx, p.pt_idx, where="device")
     _plans_equal(host, dev)
     assert dev.fused == 1 and dev.fused_slots == 7 and dev.far is not None
-    near = np.zeros(n, dtype=bool)
-    near[dev.read("fz_pt")] = True
-    assert near[kinds == 0].all()          # short tracks
-    assert not near[kinds == 1].any()      # long tracks
-    assert near[kinds == 2].all()          # distant camera sets that many points share: windows of their own
-    assert not near[kinds == 3].any()      # camera sets of a single point
+    near0 = np.zeros(n, dtype=bool)
+    near0[dev.read("fz_pt")] = True
+    near1 = np.zeros(n, dtype=bool)
+    near1[dev.read("fz_pt", cls=1)] = True
+    assert not (near0 & near1).any()
+    assert near0[kinds == 0].all()          # short tracks: windows of 7 consecutive cameras
+    assert not near0[kinds == 1].any()      # long tracks (9..14 cameras): windows of 16 where enough of them share one, else far
+    assert near0[kinds == 2].all()          # distant camera sets that many points share: windows of their own
+    assert not near0[kinds == 3].any()      # camera sets of a single point
+    print("long tracks in windows of 16:", int(near1[kinds == 1].sum()), "of", int((kinds == 1).sum()), dev.classes[1])
+    if expect_wide:
+        assert dev.classes[1]["on"] and near1[kinds == 1].sum() * 2 > (kinds == 1).sum()
+    near = near0 | near1
     assert np.array_equal(dev.read("far_pt"), np.flatnonzero(~near))
     assert dev.far.n == int((~near).sum()) and dev.far.n_obs == int((~near)[p.pt_idx].sum())
     _compare_paths(p, expect_far=True, where=where)
 
 
-@pytest.mark.parametrize("visibility,m,n", [("tracks", 60, 20000), ("mixed", 50, 6000)])
+@pytest.mark.parametrize("m,n,k", [(40, 12000, (9, 16)), (30, 6000, (10, 13)), (64, 30000, (3, 16))])
+def test_windows_of_sixteen_cameras(m, n, k):
+    """Points seen by 9..16 consecutive cameras: the class of near points with windows of 16 cameras (16
+    lanes per point, 4 points per step), alone and beside the class with windows of up to 8."""
+    from sfm_amd import synthetic
+    from sfm_amd.device import Plan
+
+    p = synthetic.make_problem(m, n, k, visibility="banded", seed=m, shuffle_ids=True)
+    host = Plan(p.cam_idx, p.pt_idx, where="host")
+    dev = Plan(p.cam_idx, p.pt_idx, where="device")
+    _plans_equal(host, dev)
+    c1 = dev.classes[1]
+    assert dev.fused == 1 and c1["on"] and c1["slots"] == 16 and c1["n_near"] > 0
+    so = dev.read("slot_obs", cls=1).reshape(-1, 16)
+    key_of_pos = np.repeat(dev.read("run_key", cls=1), np.diff(dev.read("run_pt0", cls=1)))
+    kc = dev.read("key_cam", cls=1).reshape(-1, 16)
+    pos, sl = np.nonzero(so >= 0)
+    obs = so[pos, sl]
+    assert np.unique(obs).size == obs.size
+    assert np.array_equal(p.pt_idx[obs], dev.read("fz_pt", cls=1)[pos]) and np.array_equal(p.cam_idx[obs], kc[key_of_pos[pos], sl])
+    counts = np.bincount(p.pt_idx, minlength=n)
+    assert (counts[dev.read("fz_pt", cls=1)] > dev.fused_slots).all() or dev.classes[0]["n_near"] == 0
+    print("classes", dev.classes, "far", dev.n_far)
+    _compare_paths(p)
+
+
+@pytest.mark.parametrize("visibility,m,n", [("tracks", 60, 20000), ("mixed", 50, 6000), ("long", 40, 12000)])
 def test_general_iterations_against_oracle(visibility, m, n):
     """Two iterations of the loop on plans with far points against the numpy oracle: the state path and
     the camera-pair path (bars of tests/test_gpu_fused.py::test_fused_iteration_against_oracle)."""
@@ -189,6 +226,8 @@ def test_general_iterations_against_oracle(visibility, m, n):
 
     if visibility == "tracks":
         p = synthetic.make_problem(m, n, 6, visibility="tracks", seed=11)
+    elif visibility == "long":
+        p = synthetic.make_problem(m, n, (9, 16), visibility="banded", seed=4, shuffle_ids=True)
     else:
         p, _ = mixed_problem(m, n, 5)
     R, T, X = p.R.copy(), p.T.copy(), p.X.copy()
@@ -196,7 +235,8 @@ def test_general_iterations_against_oracle(visibility, m, n):
     costs = {}
     for fused in (1, 0):
         prob = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true)
-        assert prob.plan.fused == 1 and prob.plan.far is not None and prob.from_state
+        assert prob.plan.fused == 1 and prob.from_state
+        assert (prob.plan.far is not None) == (visibility != "long")
         prob.plan.set_fused(fused)
         costs[fused] = []
         for it in range(2):
@@ -210,8 +250,11 @@ def test_general_iterations_against_oracle(visibility, m, n):
             assert relerr(prob.delta_a.cpu().numpy(), da_ref) < 1e-7
             assert relerr(prob.delta_b.cpu().numpy(), db_ref) < 1e-7
         assert relerr(prob.points(), X) < 1e-8
+    # (the two paths against each other: 1e-9, as in tests/test_gpu_fused.py; 5e-9 on the problem of long
+    # tracks, whose cost rises by half per iteration - the reference's loop diverges there - and with it
+    # every rounding difference of the first step)
     for a, b in zip(costs[0], costs[1]):
-        assert abs(a - b) <= 1e-9 * a, costs
+        assert abs(a - b) <= (5e-9 if visibility == "long" else 1e-9) * a, costs
 
 
 @pytest.mark.parametrize("case", ["ba_4x16_bigrot", "ba_8x400", "ba_20x3000", "ba_6x3000_long", "real_box", "real_boot"])
@@ -257,6 +300,6 @@ def test_patterns_without_a_fused_path():
     for where in ("host", "device"):
         pl = Plan(p.cam_idx, p.pt_idx, where=where)
         assert pl.fused == 0 and pl.n_near == 0 and pl.far is None
-    # nine consecutive cameras do not fit a window
-    r = synthetic.make_problem(30, 3000, 9, visibility="banded", seed=3)
+    # seventeen consecutive cameras do not fit a window
+    r = synthetic.make_problem(40, 3000, 17, visibility="banded", seed=3)
     assert Plan(r.cam_idx, r.pt_idx).fused == 0

@@ -22,18 +22,20 @@ def checker(tmp_path_factory):
 
 
 @pytest.mark.parametrize("args", [
-    (50, 20000, 8, 0, 1, 0),        # uniform visibility: camera sets do not repeat, every point is far, no fused path
+    (200, 20000, 8, 0, 1, 0),       # uniform visibility: camera sets do not repeat, every point is far, no fused path
+    (50, 20000, 8, 0, 1),           # uniform over fewer cameras: some points fit windows of 16 consecutive cameras
     (20, 2000, 6, 0, 1),            # few cameras, uniform: some camera sets repeat often enough for windows of their own
     (20, 2000, 6, 1, 1, 1, 100),    # banded around a moving centre
     (20, 2000, 6, 2, 1, 1, 100),    # first camera ascends: windows of 6 cameras
     (60, 30000, 8, 2, 5, 1, 100),   # windows of 8 cameras
     (90, 30000, 7, 2, 6, 1, 100),   # windows of 7
     (12, 5000, 3, 2, 7, 1, 100),    # windows of 4, several first-cameras per window
-    (200, 100000, 9, 1, 2, 1, 80),  # split blocks; points with 9 cameras are far
+    (200, 100000, 9, 1, 2, 1, 100), # split blocks; points with 9 cameras go to the class with windows of 16
+    (60, 30000, 14, 2, 5, 1, 100),  # up to 14 consecutive cameras: both classes
     (3, 50, 3, 0, 3),
     (40, 400, 30, 0, 4, 0),         # many views per point
     (90, 30000, 7, 3, 6, 1, 100),   # banded with shuffled point ids
-    (200, 100000, 8, 4, 2, 1, 70),  # tracks of geometric length up to 30, ids in random order
+    (200, 100000, 8, 4, 2, 1, 90),  # tracks of geometric length up to 30, ids in random order: both classes and far points
     (100, 50000, 6, 5, 3, 1, 99),   # distant camera sets shared by many points: windows of their own
 ])
 def test_plan_invariants(checker, args):
