@@ -6,7 +6,7 @@ RUN=$1; RT=$2
 cd "$(dirname "$0")/.."
 cp "$(ls -t gpurun_out/prof_${RUN}/*/*kernel_stats.csv | head -1)" profiles/${RT}_c4_banded_kernel_stats.csv
 cp gpurun_out/${RUN}_prof_summary.txt profiles/${RT}_c4_banded_kernel_summary.txt
-for n in c4_banded c4_uniform venice_banded; do
+for n in c4_banded c4_tracks c4_uniform venice_banded; do
   cp gpurun_out/${RUN}_${n}_pmc_fetch.txt profiles/${RT}_${n}_pmc_fetch_size.txt
   cp gpurun_out/${RUN}_${n}_pmc_write.txt profiles/${RT}_${n}_pmc_write_size.txt
 done
@@ -15,6 +15,7 @@ for x in triangulate.json pnp.json; do [ -f gpurun_out/${RUN}_$x ] && cp gpurun_
 [ -f gpurun_out/${RUN}_setup.txt ] && grep "^c4_" gpurun_out/${RUN}_setup.txt > profiles/${RT}_setup.txt
 [ -f gpurun_out/${RUN}_dropin.txt ] && grep " rep [0-9]*: optimize_using_BA" gpurun_out/${RUN}_dropin.txt > profiles/${RT}_dropin.txt
 python3 scripts/pmc_to_json.py profiles/${RT}_c4_banded_pmc_fetch_size.txt profiles/${RT}_c4_banded_pmc_write_size.txt c4_500x300k/banded profiles/${RT}_pmc_traffic.json
+python3 scripts/pmc_to_json.py profiles/${RT}_c4_tracks_pmc_fetch_size.txt profiles/${RT}_c4_tracks_pmc_write_size.txt c4_500x300k/tracks profiles/${RT}_pmc_traffic.json
 python3 scripts/pmc_to_json.py profiles/${RT}_c4_uniform_pmc_fetch_size.txt profiles/${RT}_c4_uniform_pmc_write_size.txt c4_500x300k/uniform profiles/${RT}_pmc_traffic.json
 python3 scripts/pmc_to_json.py profiles/${RT}_venice_banded_pmc_fetch_size.txt profiles/${RT}_venice_banded_pmc_write_size.txt venice1800/banded profiles/${RT}_pmc_traffic.json
 python3 scripts/make_profiles_readme.py ${RT}

@@ -18,22 +18,38 @@ def bench(name):
 
 
 rows = [("default", "c4_500x300k banded (the `bench.py` default)"),
-        ("default_rows", "c4_500x300k banded, rows of A materialised (`SFM_BA_STATE=0`)"), ("c4_500x300k_uniform", "c4_500x300k uniform"),
-        ("ladybug50_banded", "ladybug50 banded"), ("ladybug50_uniform", "ladybug50 uniform"),
-        ("venice1800_banded", "venice1800 banded"),
-        ("venice1800_banded_rows", "venice1800 banded, rows of A materialised (`SFM_BA_STATE=0`)"), ("venice1800_uniform", "venice1800 uniform (dense S, 12 600 unknowns)")]
+        ("default_shuffled", "c4_500x300k banded, point ids relabelled at random (`--shuffle-ids`)"),
+        ("default_rows", "c4_500x300k banded, rows of A materialised (`SFM_BA_STATE=0`)"),
+        ("c4_500x300k_tracks", "c4_500x300k tracks"), ("c4_500x300k_uniform", "c4_500x300k uniform"),
+        ("ladybug50_banded", "ladybug50 banded"), ("ladybug50_tracks", "ladybug50 tracks"), ("ladybug50_uniform", "ladybug50 uniform"),
+        ("venice1800_banded", "venice1800 banded"), ("venice1800_tracks", "venice1800 tracks"),
+        ("venice1800_uniform", "venice1800 uniform (dense S, 12 600 unknowns)")]
 for w in ("c4_500x300k", "venice1800"):
     for v, what in (("loop", "one lap closing a loop"), ("closures", "two laps over the same places")):
-        rows.append((f"{w}_{v}", f"{w} {what}, split: near points fused, far points camera-pair, solve in the folded order"))
-        rows.append((f"{w}_{v}_folded", f"{w} {what}, all cameras in the folded order (`SFM_BA_SPLIT=0`)"))
+        rows.append((f"{w}_{v}", f"{w} {what}, cameras in the folded order"))
         rows.append((f"{w}_{v}_acquisition", f"{w} {what}, cameras in acquisition order (`SFM_BA_REORDER=0`)"))
+
+
+def rate(g):
+    """Stage rate in GB/s of algorithmic bytes; in brackets when the stage forms the rows of A itself
+    (fp64-bound: the figure prices replaced work and is not a bandwidth)."""
+    if g.get("GBps") is not None:
+        return "%.0f" % g["GBps"]
+    if g.get("priced_GBps") is not None:
+        return "[%.0f]" % g["priced_GBps"]
+    return "-"
+
+
 out = [f"# profiles — round {tag[1:]} evidence (MI355X, one GPU)", "",
        "Produced by `bash scripts/gpu_evidence.sh <tag>` on the GPU box; this file is generated from the files next to it",
        "by `scripts/make_profiles_readme.py`.", "",
        "## Bench lines (`bench.py`, 10 timed Gauss-Newton iterations after 3 warm-up iterations)", "",
-       "GB/s price the bytes the loop has to move (136 / 152 / 120 per observation: B is read out of A and never written).", "",
-       "Where the rows of A are formed inside the assembly kernel, the two stages appear as one figure in parentheses.", "",
-       "| workload | cameras x points x observations | assembly | ms/iteration (with / without event records) | observations/s | reduced solve ms (path) | Jacobian / assembly / back-substitution, GB/s |",
+       "Stage rates price the bytes the loop has to move (136 / 152 / 120 per observation: B is read out of A and never",
+       "written) over the HIP-event time of the stage's kernels.  A stage whose kernels read the rows of A from HBM is",
+       "HBM-bound and the figure is its bandwidth.  A stage whose kernels form the rows themselves is bound by the fp64",
+       "pipe: its figure is in square brackets, prices the work it replaces and is not a bandwidth (it may exceed 8000).",
+       "Where the rows of A are formed inside the assembly kernel, Jacobian and assembly are one stage.", "",
+       "| workload | cameras x points x observations | assembly | ms/iteration (with / without event records) | observations/s | reduced solve ms (path) | stage: time us, rate GB/s |",
        "|---|---|---|---|---|---|---|"]
 for key, label in rows:
     d = bench(key)
@@ -41,10 +57,7 @@ for key, label in rows:
         continue
     g = d["roofline"]["groups"]
     c = d["config"]
-    if "jacobian+assembly" in g:
-        stages = "(%.0f) / %.0f" % (g["jacobian+assembly"]["GBps"], g["back_substitution"]["GBps"])
-    else:
-        stages = "%.0f / %.0f / %.0f" % (g["jacobian"]["GBps"], g["assembly"]["GBps"], g["back_substitution"]["GBps"])
+    stages = "; ".join("%s %.0f us, %s" % (nm, 1e3 * gg["ms"], rate(gg)) for nm, gg in g.items())
     order = c.get("camera_order", "")
     out.append("| %s | %d x %d x %d | %s | %.3f / %.3f | %.3g | %.3f (%s) | %s |" % (
         label, c["cameras"], c["points"], c["observations"],
@@ -54,27 +67,34 @@ d = bench("default")
 if d is not None:
     r = d["roofline"]
     out += ["", "## Default bench line: roofline and CPU baseline", "",
-            f"* dominant HBM-bound stage: {r['kernel']}",
-            "* algorithmic bytes per iteration %.1f MB -> achieved %.0f GB/s = %.1f %% of the %.0f GB/s HBM peak"
-            " (with B priced as a materialised array: %.0f GB/s = %.1f %%)" % (
-                r["groups"][max(r["groups"], key=lambda k: r["groups"][k]["ms"])]["bytes"] / 1e6, r["achieved"],
-                100 * r["frac"], r["peak"], r.get("achieved_with_B", 0.0), 100 * r.get("frac_with_B", 0.0)),
-            "* measured HBM traffic of that stage (PMC, below): %s" % (
-                "%.1f MB per iteration" % (r["traffic"] / 1e6) if r.get("traffic") else "not collected for this line"),
-            ]
+            f"* dominant stage: {r['kernel']}",
+            "* bound: %s; achieved %.3g %s = %.1f %% of the %.4g %s peak" % (
+                r["bound"], r["achieved"], r["unit"], 100 * r["frac"], r["peak"], r["unit"])]
+    if r["bound"] == "mfma":
+        out += ["* its algorithmic bytes (the two stages it replaces) retire at %.0f GB/s (%.0f with B priced as a materialised array);"
+                " that is a rate of work, not of bytes moved" % (r["achieved_algorithmic"], r["achieved_algorithmic_with_B"])]
+    out += ["* measured HBM traffic of that stage (PMC, below): %s" % (
+                "%.1f MB per iteration = %.0f GB/s = %.1f %% of the HBM peak" % (
+                    r["traffic"] / 1e6, r["groups"][max(r["groups"], key=lambda k: r["groups"][k]["ms"])]["traffic_GBps"],
+                    100 * r["groups"][max(r["groups"], key=lambda k: r["groups"][k]["ms"])]["traffic_GBps"] / 8000.0)
+                if r.get("traffic") else "not collected for this line")]
     for gname, g in r["groups"].items():
-        out.append("* %s: %.1f us, algorithmic %.1f MB (%.0f GB/s)%s" % (
-            gname, 1e3 * g["ms"], g["bytes"] / 1e6, g["GBps"],
+        out.append("* %s (bound: %s): %.1f us, algorithmic %.1f MB (%s GB/s)%s" % (
+            gname, g["bound"], 1e3 * g["ms"], g["algorithmic_bytes"] / 1e6, rate(g),
             ", measured traffic %.1f MB (%.0f GB/s)" % (g["traffic"] / 1e6, g["traffic_GBps"]) if g.get("traffic") else ""))
     if r.get("note"):
         out.append("* note: " + r["note"])
-    u = d.get("uniform_visibility")
-    if u:
-        ug = u["groups"]
-        out.append("* same workload, uniform visibility (sub-record of the same line): %.3f ms per iteration; Jacobian %.1f us, "
-                   "assembly %.1f us (%s), back-substitution %.1f us, solve %.3f ms (%s)" % (
-                       u["ms_per_step"], 1e3 * ug["jacobian"]["ms"], 1e3 * ug["assembly"]["ms"],
-                       "+".join(ug["assembly"]["kernels"]), 1e3 * ug["back_substitution"]["ms"], u["solve"]["ms"], u["solve"]["path"]))
+    for key, what in (("shuffled_ids", "point ids relabelled at random"), ("tracks_visibility", "track visibility"),
+                      ("uniform_visibility", "uniform visibility"), ("loop_visibility", "one lap closing a loop"),
+                      ("venice1800_banded", "the 1 M-point workload")):
+        u = d.get(key)
+        if not u:
+            continue
+        ug = u["roofline"]["groups"]
+        out.append("* sub-record `%s` (%s): %.3f ms per iteration, %.3g observations/s; %s; solve %.3f ms (%s); assembly: %s" % (
+            key, what, u["ms_per_step"], u["value"],
+            "; ".join("%s %.1f us (%s, %s GB/s)" % (nm, 1e3 * gg["ms"], gg["bound"], rate(gg)) for nm, gg in ug.items()),
+            u["solve"]["ms"], u["solve"]["path"], u["assembly"]))
     cb = d.get("cpu_baseline")
     if cb:
         out += ["* CPU baseline (`kind: %s`, %d BLAS threads): %.3g observations/s — %s" % (
@@ -134,10 +154,10 @@ for name, title in (("setup", "Handing a problem over as host arrays (`scripts/t
 out += ["", "## Files", "",
         f"* `{tag}_bench_*.json` — the JSON line of each bench run",
         f"* `{tag}_c4_banded_kernel_stats.csv`, `{tag}_c4_banded_kernel_summary.txt` — rocprofv3 kernel statistics of the default bench",
-        f"* `{tag}_*_pmc_fetch_size.txt`, `{tag}_*_pmc_write_size.txt`, `{tag}_pmc_traffic.json` — PMC passes (default workload, the same with uniform visibility, venice1800 banded)",
+        f"* `{tag}_*_pmc_fetch_size.txt`, `{tag}_*_pmc_write_size.txt`, `{tag}_pmc_traffic.json` — PMC passes (default workload, the same with track and with uniform visibility, venice1800 banded)",
         f"* `{tag}_triangulate.json`, `{tag}_pnp.json` — triangulation and PnP benchmark lines",
         f"* `{tag}_setup.txt`, `{tag}_dropin.txt` — host-side timings of plan build / uploads and of the drop-in call",
-        "* `README_r01.md` and the `r01_*` files — the previous round's evidence, for comparison",
+        "* `README_r01.md`, `README_r02.md` and the `r01_*`, `r02_*` files — the earlier rounds' evidence, for comparison",
         ""]
 open(os.path.join(P, "README.md"), "w").write("\n".join(out))
 print("wrote profiles/README.md")

@@ -20,8 +20,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # of S and solves with the general Cholesky - blocks this rank's points never touch arrive from the peer.
 # "wide": 12 consecutive cameras per point, half bandwidth 83 of 1120 unknowns: lower-triangle exchange,
 # then the cyclic reduction on superblocks of 128.
+# "loop": one lap that closes on itself; every rank keeps the cameras in the folded order that the
+# unsharded lists give (computed by each rank alike before the points are dealt out), in which the
+# system is a narrow band again: packed exchange, cyclic reduction.
 PROBLEMS = {"small": (12, 3000, 4, "banded"), "chain7": (60, 6000, 5, "banded"), "dense": (14, 3000, 4, "uniform"),
-            "wide": (160, 8000, 12, "banded")}
+            "wide": (160, 8000, 12, "banded"), "loop": (60, 6000, 4, "loop")}
 
 
 def _worker(rank, world, port, q, which="small"):
@@ -42,9 +45,16 @@ def _worker(rank, world, port, q, which="small"):
         m, n, k, vis = PROBLEMS[which]
         full = synthetic.make_problem(m, n, k=k, visibility=vis, seed=6)
         loc, (p0, p1) = local_problem(full, rank, world)
+        order = None
+        if vis == "loop":
+            from sfm_amd import ordering
+
+            hb_nat = ordering.half_bandwidth(np.arange(m), full.cam_idx, full.pt_idx, full.n)
+            hb_new, pos, order = ordering.narrowest_order(full.cam_idx, full.pt_idx, m, full.n, hb_nat)
+            assert pos is not None and hb_new <= 64 < hb_nat
         prob = DeviceProblem(loc.K, loc.R, loc.T, loc.X, loc.cam_idx, loc.pt_idx, loc.x_true, n_cams=full.m,
-                             group=dist.group.WORLD, check=False)
-        assert prob.band_sharded == (vis == "banded" and k <= 9)
+                             group=dist.group.WORLD, check=False, cam_order=order)
+        assert prob.band_sharded == ((vis == "banded" and k <= 9) or vis == "loop")
         if not prob.band_sharded:
             assert prob.half_bandwidth > 64
         c0 = prob.cost()
@@ -55,7 +65,7 @@ def _worker(rank, world, port, q, which="small"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("which", ["small", "chain7", "dense", "wide"])
+@pytest.mark.parametrize("which", ["small", "chain7", "dense", "wide", "loop"])
 def test_two_ranks_match_single_process(which):
     import torch.multiprocessing as mp
 
@@ -78,7 +88,8 @@ def test_two_ranks_match_single_process(which):
 
     m, n, k, vis = PROBLEMS[which]
     full = synthetic.make_problem(m, n, k=k, visibility=vis, seed=6)
-    one = DeviceProblem(full.K, full.R, full.T, full.X, full.cam_idx, full.pt_idx, full.x_true)
+    one = DeviceProblem(full.K, full.R, full.T, full.X, full.cam_idx, full.pt_idx, full.x_true, reorder=(vis == "loop"))
+    assert (one.cam_order is not None) == (vis == "loop")
     c0 = one.cost()
     costs = one.run(max_iter=3, threshold=0.0)
     R1, T1, _, _ = one.cameras()
