@@ -69,6 +69,8 @@ int main() {
   for (int kk = 0; kk < 4; ++kk)
     printf(" kk=%d factor %lld  barrier %lld  jobs %lld  barrier %lld\n", kk, st[2 + 4 * kk] - st[1 + 4 * kk],
            st[3 + 4 * kk] - st[2 + 4 * kk], st[4 + 4 * kk] - st[3 + 4 * kk], (kk < 3 ? st[5 + 4 * kk] : st[16]) - st[4 + 4 * kk]);
+  for (int kk = 0; kk < 4; ++kk)
+    printf(" kk=%d load %lld factor16 %lld store %lld\n", kk, st[20 + kk] - st[1 + 4 * kk], st[24 + kk] - st[20 + kk], st[2 + 4 * kk] - st[24 + kk]);
   printf(" loop %lld, tail jobs %lld, barrier %lld, stores %lld, all %lld\n", st[16] - st[0], st[17] - st[16], st[18] - st[17], st[19] - st[18], st[19] - st[0]);
   // check: L L^T = S and invL L = I
   std::vector<double> Lh((n + 1) * n), Ih(64 * 64);

@@ -11,7 +11,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsfm_ba.so")
+# (SFM_BA_VARIANT=<name> loads a diagnostic build csrc/libsfm_ba_<name>.so made by csrc/build.py instead)
+_VARIANT = os.environ.get("SFM_BA_VARIANT", "")
+LIB_PATH = os.path.join(_HERE, "csrc", f"libsfm_ba_{_VARIANT}.so" if _VARIANT else "libsfm_ba.so")
 
 OK = 0
 EINVAL, EHIP, ENONUNIQUE, EMISSING_POINT, EMISSING_VIEW, ENOTPD, ETOOBIG = -1, -2, -3, -4, -5, -6, -7

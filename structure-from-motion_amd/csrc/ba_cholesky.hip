@@ -218,7 +218,9 @@ __device__ __forceinline__ void diag_core(double* __restrict__ L, double* __rest
         a[c] = from_l ? L[row * LDT + o + c] : 0.0;
         if (wave == 1 && lane - SB == c) a[c] = 1.0;
       }
+      STAMP(20 + kk);
       const int bad = factor16(a, lane);
+      STAMP(24 + kk);
       if (wave == 0) {
         if (row < NB) {
 #pragma unroll

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/sfm_ba.h"
 
@@ -63,7 +64,12 @@ inline int fz_choose_slots(const int64_t obs_by_k[9], const int64_t obs_by_span[
 }
 // a run is cut wherever the position is a multiple of this: one wave per range of pmax near points
 inline int fz_pmax_for(int32_t n_near) {
-  const int pm = ((n_near + 2047) / 2048 + 7) & ~7;
+  static const int ranges = [] {
+    const char* v = getenv("SFM_BA_FZ_RANGES");
+    const int r = v ? atoi(v) : 0;
+    return r >= 64 ? r : 2048;
+  }();
+  const int pm = ((n_near + ranges - 1) / ranges + 7) & ~7;
   return pm < 32 ? 32 : (pm > kFzMaxPmax ? kFzMaxPmax : pm);
 }
 // A class is kept when its runs hold enough points on average (a run costs a partial result of its own:

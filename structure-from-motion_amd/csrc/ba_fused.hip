@@ -495,7 +495,7 @@ __global__ __launch_bounds__(64, WPS) void k_fused_state(
     if (REGS)                                                                                               \
       fz_rows_from_state<true, false>(rreg, preg, X0, X1, X2, XT, HAS, av);                                 \
     else                                                                                                    \
-      fz_rows_from_state<true, true>(reinterpret_cast<const double2*>(sRec + RS * s),                       \
+      fz_rows_from_state<true, true>(reinterpret_cast<const double2*>(sRec + RS * s),                     \
                                      reinterpret_cast<const double2*>(sRec + LPP * RS + 12 * s), X0, X1, X2, XT, HAS, av); \
   } while (0)
   const int pt_first = f0 + p < n_pts ? f0 + p : n_pts - 1;
