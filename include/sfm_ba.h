@@ -195,6 +195,20 @@ int sfm_ba_schur_assemble(const sfm_ba_plan* plan, const double* d_A, const doub
                           double* d_eps_a, double* d_V_inv, double* d_eps_b, double* d_cam_red,
                           void* d_workspace, void* stream);
 
+/* The same assembly (calc_V_inv ... calc_e, src/sparse_ba.py:147-271, no weights, no by-products) for any
+ * visibility inside a loop that owns the state: d_A holds the rows sfm_ba_jacobian wrote from the state
+ * (d_cam_blk, d_X) - the per-point stage takes the point blocks out of them - and the camera-pair products
+ * A_j^T T A_k are formed from the state inside the kernel: an entry costs its point's position and V^-1
+ * (80 bytes) and an index instead of two rows of A and a coupling (256 bytes), and no coupling is written.
+ * The rows formed there agree with d_A's to a few units in the last place (one reciprocal per quotient rule
+ * instead of a division per entry).  Writes the lower triangle of d_S, row 7m, d_e (may be NULL), d_V_inv,
+ * d_eps_b and - d_cam_ssq [m], may be NULL - per camera the sum of squared residuals of its observations
+ * (see sfm_ba_schur_assemble_state).  mu_u as in sfm_ba_schur_assemble. */
+int sfm_ba_schur_assemble_pairs_state(const sfm_ba_plan* plan, const double* d_A, const double* d_cam_blk,
+                                      const double* d_X, const double* d_x_true, const double* d_x_pred, double mu,
+                                      double mu_u, double* d_S, double* d_e, double* d_V_inv, double* d_eps_b,
+                                      double* d_cam_ssq, void* d_workspace, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Jacobian blocks and Schur assembly in one pass, for plans with a fused path (sfm_ba_plan_state_path
  * returns 1): the rows of A and the residuals - compute_A_B and the projection of get_indices

@@ -41,6 +41,7 @@ SYMBOLS = {
     "sfm_ba_plan_far": (_vp, [_vp]),
     "sfm_ba_plan_state_path": (_int, [_vp]),
     "sfm_ba_back_substitute_state": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _f64, _vp, _vp]),
+    "sfm_ba_schur_assemble_pairs_state": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_ba_schur_assemble_state": (_int, [_vp, _vp, _vp, _vp, _vp, _f64, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_ba_calc_W_Y": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_ba_add_diagonal": (_int, [_vp, _i32, _f64, _vp]),

@@ -47,6 +47,17 @@ int sfm_ba_schur_assemble(const sfm_ba_plan* plan, const double* d_A, const doub
                          d_eps_b, d_cam_red, d_workspace, static_cast<hipStream_t>(stream));
 }
 
+int sfm_ba_schur_assemble_pairs_state(const sfm_ba_plan* plan, const double* d_A, const double* d_cam_blk,
+                                      const double* d_X, const double* d_x_true, const double* d_x_pred, double mu,
+                                      double mu_u, double* d_S, double* d_e, double* d_V_inv, double* d_eps_b,
+                                      double* d_cam_ssq, void* d_workspace, void* stream) {
+  if (!plan || !d_A || !d_cam_blk || !d_X || !d_x_true || !d_x_pred || !d_S || !d_V_inv || !d_eps_b || !d_workspace)
+    return SFM_BA_EINVAL;
+  if (!(mu >= 0.0) || !(mu_u >= 0.0)) return SFM_BA_EINVAL;
+  return launch_assemble_pairs_state(plan, d_A, d_cam_blk, d_X, d_x_true, d_x_pred, mu, mu_u, d_S, d_e, d_V_inv, d_eps_b,
+                                     d_cam_ssq, d_workspace, static_cast<hipStream_t>(stream));
+}
+
 int sfm_ba_plan_state_path(const sfm_ba_plan* plan) { return plan && fz_state_applies(plan) ? 1 : 0; }
 
 int sfm_ba_schur_assemble_state(const sfm_ba_plan* plan, const double* d_cam_blk, const double* d_P, const double* d_X,

@@ -15,6 +15,8 @@ constexpr int kCamChunk = 1024;    // observations per per-camera work item
 constexpr int kCamThreads = 128;   // threads of a per-camera work item
 constexpr int kPairChunk = 512;   // (obs, obs) entries per camera-pair work item (one wave each)
 constexpr int kPairPad = 64;
+constexpr int kPointRec = 10;       // doubles per point record of the camera-pair kernel that forms its rows itself:
+                                    // position (3), V^-1 as 00 01 02 11 12 22 (6), one of padding (80 bytes)
 constexpr int kPairPartStride = 64;  // doubles per partial result of a split block: 7x7 block, e_j (49..55), the
                                      // camera's sum of squared residuals (56); diagonal blocks only fill 49..56
 
@@ -189,6 +191,7 @@ struct sfm_ba_plan {
   int32_t* d_blk_k = nullptr;
   int64_t n_entries = 0;
   sfmba::PairEntry* d_entries = nullptr;
+  int32_t* d_ent_pt = nullptr;    // [n_entries] point (of this plan) the entry's two observations belong to
   // pair work items: chunk of one block's entries
   int32_t n_pair_items = 0;
   int32_t* d_pit_blk = nullptr;
@@ -223,7 +226,7 @@ struct sfm_ba_plan {
   int32_t force_parts = 0;        // this plan is the far plan of another: every block writes partial results
   int64_t device_bytes = 0;
   // workspace section offsets (bytes)
-  int64_t ws_g = 0, ws_T = 0, ws_q = 0, ws_campart = 0, ws_spart = 0, ws_fzero = 0, ws_far_A = 0,
+  int64_t ws_g = 0, ws_T = 0, ws_q = 0, ws_campart = 0, ws_spart = 0, ws_prec = 0, ws_fzero = 0, ws_far_A = 0,
           ws_far_xt = 0, ws_far_xp = 0, ws_far = 0, ws_total = 0;
 };
 
@@ -275,9 +278,17 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
 // the fused path of launch_assemble (plan with runs, no weights, no by-products, B taken from A)
 int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* xt, const double* xp, double mu,
                           double mu_u, double* S, double* e, double* Vinv, double* eps_b, void* ws, hipStream_t st);
-// the camera-pair path of a far plan (see sfm_ba_plan::far): partial results only, points renumbered by pt_map
+// the camera-pair path of a far plan (see sfm_ba_plan::far): partial results only, points renumbered by pt_map.
+// blk / X given: the camera-pair products are formed from the state (k_pair_state) instead of gathered rows of A
 int launch_assemble_parts(const sfm_ba_plan* p, const int32_t* pt_map, const double* A, const double* xt,
-                          const double* xp, double mu, double* Vinv, double* eps_b, void* ws, hipStream_t st);
+                          const double* xp, double mu, double* Vinv, double* eps_b, void* ws, const double* blk,
+                          const double* X, hipStream_t st);
+// the camera-pair path of a whole plan in the loop: A as sfm_ba_jacobian wrote it from this state (the per-point
+// stage and the back-substitution read it), camera-pair products formed from the state; S, e, the per-camera
+// squared residuals
+int launch_assemble_pairs_state(const sfm_ba_plan* p, const double* A, const double* blk, const double* X,
+                                const double* xt, const double* xp, double mu, double mu_u, double* S, double* e,
+                                double* Vinv, double* eps_b, double* ssq, void* ws, hipStream_t st);
 int launch_back_substitute_mapped(const sfm_ba_plan* p, const int32_t* pt_map, const double* A, const double* Vinv,
                                   const double* eps_b, const double* da, double* db, double* Xupd, double x_step,
                                   hipStream_t st);

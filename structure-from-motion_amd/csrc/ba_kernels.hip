@@ -9,9 +9,11 @@
 //   S          dense (7m+1) x 7m row-major; row 7m carries the right-hand side e
 //
 // Every reduction runs in a fixed order (no atomics), so results are reproducible bit for bit.
+#include <cstdlib>
 #include <mutex>
 
 #include "ba_common.h"
+#include "ba_rows.h"
 
 namespace sfmba {
 
@@ -371,7 +373,8 @@ __device__ __noinline__ void point_long(int t, int p0, int pid, int s0, int ns, 
                                         const double* __restrict__ xt, const double* __restrict__ xpred,
                                         const double* __restrict__ wgt, double mu, int fold_u,
                                         double* __restrict__ Vinv, double* __restrict__ eps_b, double* __restrict__ g,
-                                        double* __restrict__ qsq, double* __restrict__ T, double* sRed /* 256 x 9 */) {
+                                        double* __restrict__ qsq, double* __restrict__ T, const double* __restrict__ X,
+                                        double* __restrict__ prec, double* sRed /* 256 x 9 */) {
   double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int s = t; s < ns; s += 256) {
     ObsTerms o;
@@ -411,6 +414,12 @@ __device__ __noinline__ void point_long(int t, int p0, int pid, int s0, int ns, 
     vo[6] = iv[2]; vo[7] = iv[4]; vo[8] = iv[5];
     double* eo = eps_b + 3 * (int64_t)pid;
     eo[0] = a[6]; eo[1] = a[7]; eo[2] = a[8];
+    if (prec) {
+      double* pr = prec + kPointRec * (int64_t)p0;
+      const double* xq = X + 3 * (int64_t)pid;
+      pr[0] = xq[0]; pr[1] = xq[1]; pr[2] = xq[2];
+      pr[3] = iv[0]; pr[4] = iv[1]; pr[5] = iv[2]; pr[6] = iv[3]; pr[7] = iv[4]; pr[8] = iv[5];
+    }
   }
   const int64_t k = ns;
   for (int ai = t; ai < ns; ai += 256) {
@@ -426,6 +435,7 @@ __device__ __noinline__ void point_long(int t, int p0, int pid, int s0, int ns, 
     const double h10 = o.bp[3] * iv[0] + o.bp[4] * iv[1] + o.bp[5] * iv[2];
     const double h11 = o.bp[3] * iv[1] + o.bp[4] * iv[3] + o.bp[5] * iv[4];
     const double h12 = o.bp[3] * iv[2] + o.bp[4] * iv[4] + o.bp[5] * iv[5];
+    if (!T) continue;  // (the couplings are formed by the camera-pair kernel itself)
     int64_t ts = (int64_t)tp_ptr[p0] + (int64_t)ai * k - (int64_t)ai * (ai - 1) / 2;
     for (int b = ai; b < ns; ++b, ++ts) {
       ObsTerms ob;
@@ -452,6 +462,9 @@ __device__ __noinline__ void point_long(int t, int p0, int pid, int s0, int ns, 
 // One workgroup owns a run of points with at most kGroupSlots observations; one lane per
 // observation, then one lane per point.  pt_map (may be null): id under which point p of the plan
 // keeps its V^-1 and eps_b (the far plan of a larger plan numbers its points from 0).
+// T may be null: no couplings are written.  prec (may be null, needs X): per point of the plan its
+// position and V^-1 (00 01 02 11 12 22) as one record of kPointRec doubles, what the camera-pair kernel
+// that forms its rows itself (k_pair_state) fetches per entry.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_point(
     const int32_t* __restrict__ pt_map, const int32_t* __restrict__ grp_pt, const int32_t* __restrict__ pt_ptr,
@@ -459,7 +472,8 @@ __global__ __launch_bounds__(256) void k_point(
     const int32_t* __restrict__ pair_entry, const double* __restrict__ A,
     const double* __restrict__ B, const double* __restrict__ xt, const double* __restrict__ xpred,
     const double* __restrict__ wgt, double mu, int fold_u, double* __restrict__ Vinv,
-    double* __restrict__ eps_b, double* __restrict__ g, double* __restrict__ qsq, double* __restrict__ T) {
+    double* __restrict__ eps_b, double* __restrict__ g, double* __restrict__ qsq, double* __restrict__ T,
+    const double* __restrict__ X, double* __restrict__ prec) {
   // qsq: per observation {squared residual, 0}, what the camera-pair kernel adds up per camera for the cost
   __shared__ double sBp[kGroupSlots * 6];
   __shared__ double sCon[kGroupSlots * 9];
@@ -474,7 +488,7 @@ __global__ __launch_bounds__(256) void k_point(
   const int ns = sPtr[np] - s0;
   if (ns > kGroupSlots) {  // one point with more observations than lanes (same for the whole workgroup)
     point_long(t, p0, pt_map ? pt_map[p0] : p0, s0, ns, perm, tp_ptr, pair_entry, A, B, xt, xpred, wgt, mu, fold_u, Vinv,
-               eps_b, g, qsq, T, sCon);
+               eps_b, g, qsq, T, X, prec, sCon);
     return;
   }
   if (t < np)
@@ -551,6 +565,12 @@ __global__ __launch_bounds__(256) void k_point(
     vo[6] = i02; vo[7] = i12; vo[8] = i22;
     double* eo = eps_b + 3 * (int64_t)pid;
     eo[0] = a[6]; eo[1] = a[7]; eo[2] = a[8];
+    if (prec) {
+      double* pr = prec + kPointRec * (int64_t)(p0 + t);
+      const double* xq = X + 3 * (int64_t)pid;
+      pr[0] = xq[0]; pr[1] = xq[1]; pr[2] = xq[2];
+      pr[3] = i00; pr[4] = i01; pr[5] = i02; pr[6] = i11; pr[7] = i12; pr[8] = i22;
+    }
   }
   __syncthreads();
   if (t < ns) {
@@ -568,7 +588,7 @@ __global__ __launch_bounds__(256) void k_point(
     const double h11 = bp[3] * i01 + bp[4] * i11 + bp[5] * i12;
     const double h12 = bp[3] * i02 + bp[4] * i12 + bp[5] * i22;
     const int first = sPtr[lp] - s0;
-    const int k = sPtr[lp + 1] - sPtr[lp];
+    const int k = T ? sPtr[lp + 1] - sPtr[lp] : 0;  // (no T: the couplings are formed by the camera-pair kernel itself)
     const int a = t - first;
     int64_t ts = (int64_t)tp_ptr[p0 + lp] + (int64_t)a * k - (int64_t)a * (a - 1) / 2;
     // four pairs at a time: their entry positions are fetched together, then the four rows go out
@@ -939,6 +959,179 @@ __global__ __launch_bounds__(64) void k_pair_blocks(
         S[(7 * (int64_t)k + c) * ld + 7 * j + r] = -av;
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// camera-pair blocks from the state: what k_pair_blocks computes, with the two rows of A of an entry
+// formed in the kernel (ba_rows.h) and its coupling T_ab = B_a V^-1 B_b^T formed from them, instead of
+// two rows of A and a 2 x 2 block fetched per entry.  An entry then costs its point's record (position
+// and V^-1, 80 bytes, written by k_point) and 4 bytes of index; on the diagonal also the observation's g
+// and squared residual.  The block's two camera records are the same for every lane and come through
+// the scalar cache.  One wave per work item, 64 entries per step, two phases per step:
+//   1. lane = entry: rows A_a, A_b, T, P = T A_b; A_a (2 x 7) and P (2 x 7) go to the wave's LDS
+//   2. lane = element (r, c) of the block (49 lanes), e_j[r] (7 lanes), the squared residuals (1 lane):
+//      the lane walks the step's entries in order and adds A_a[:, r] . P[:, c] (A_a[:, r] . g for e_j)
+// so every sum runs in entry order inside one lane: no reduction across lanes, reproducible bit for
+// bit.  No weights; the self pairs carry U_j (T_aa - I), as with fold_u in k_pair_blocks.
+// ------------------------------------------------------------------------------------------
+constexpr int kPairStateRec = 33;  // doubles per entry in LDS: A_a (14), P (14), g (2), squared residual, 0.5, pad (odd stride)
+
+__global__ __launch_bounds__(64, 3) void k_pair_state(
+    int n_items, const int32_t* __restrict__ pit_blk, const int32_t* __restrict__ pit_beg,
+    const int32_t* __restrict__ pit_end, const int32_t* __restrict__ pit_part, const int32_t* __restrict__ blk_j,
+    const int32_t* __restrict__ blk_k, const PairEntry* __restrict__ ent, const int32_t* __restrict__ ent_pt,
+    const double* __restrict__ cam_blk, const double* __restrict__ prec, const double* __restrict__ g,
+    const double* __restrict__ qsq, double mu_u, int m, double* __restrict__ S, double* __restrict__ e_out,
+    double* __restrict__ ssq_out, double* __restrict__ spart) {
+  __shared__ double img[64 * kPairStateRec];
+  // (same remap of the workgroup index as k_pair_blocks: every XCD walks a contiguous eighth of the items)
+  const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+  const int item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int lane = threadIdx.x;
+  const int beg = __builtin_amdgcn_readfirstlane(pit_beg[item]);
+  const int end = __builtin_amdgcn_readfirstlane(pit_end[item]);
+  const int blk = __builtin_amdgcn_readfirstlane(pit_blk[item]);
+  const int bj = __builtin_amdgcn_readfirstlane(blk_j[blk]), bk = __builtin_amdgcn_readfirstlane(blk_k[blk]);
+  const bool diag = bj == bk;
+  const double2* rj = reinterpret_cast<const double2*>(cam_blk) + (SFM_BA_CAM_BLK / 2) * (int64_t)bj;
+  const double2* rk = reinterpret_cast<const double2*>(cam_blk) + (SFM_BA_CAM_BLK / 2) * (int64_t)bk;
+  // phase 2: what this lane multiplies per entry (offsets into the entry's record)
+  //   lanes 0..48: A_a[0][r] P[0][c] + A_a[1][r] P[1][c];  49..55: A_a[0][r] g0 + A_a[1][r] g1;
+  //   56: 0.5 q + 0.5 q (the squared residual, exactly); 57..63: nothing
+  int oa0, oa1, op0, op1;
+  {
+    const int r = lane < 49 ? lane / 7 : lane - 49, c = lane < 49 ? lane - 7 * (lane / 7) : 0;
+    oa0 = r;
+    oa1 = 7 + r;
+    op0 = lane < 49 ? 14 + c : 28;
+    op1 = lane < 49 ? 21 + c : 29;
+    if (lane >= 56) {
+      oa0 = oa1 = 30;
+      op0 = op1 = 31;
+    }
+  }
+  const bool counts = lane < 49 || (diag && lane < 57);
+  double acc0 = 0.0, acc1 = 0.0;
+  for (int i0 = beg; i0 < end; i0 += 64) {
+    // ---- phase 1: this lane's entry ----
+    {
+      const int i = i0 + lane;
+      const bool live = i < end;
+      const int ic = live ? i : end - 1;
+      const double* pr = prec + kPointRec * (int64_t)ent_pt[ic];
+      const double2 x01 = ld2(pr), x2v = ld2(pr + 2), v12 = ld2(pr + 4), v34 = ld2(pr + 6);
+      const double v5 = pr[8];
+      double2 gv = make_double2(0.0, 0.0);
+      double qs = 0.0;
+      if (diag) {
+        // the second field of a diagonal block's record is 16 * observation: its entry of g and of the squared residuals
+        const unsigned ob = ent[ic].row_b >> 3;  // in doubles
+        const double2 gl = ld2(g + ob);
+        const double ql = qsq[ob];
+        gv = live ? gl : gv;
+        qs = live ? ql : 0.0;
+      }
+      double* o = img + kPairStateRec * lane;
+#ifndef SFMBA_PAIR_SKIP_P1
+      const double i00 = x2v.y, i01 = v12.x, i02 = v12.y, i11 = v34.x, i12 = v34.y, i22 = v5;
+      double2 aa[9], ab[9];
+      fz_rows_from_state<false>(rj, static_cast<const double2*>(nullptr), x01.x, x01.y, x2v.x, make_double2(0.0, 0.0), live, aa);
+#define ra_(q) (((q) & 1) ? aa[(q) >> 1].y : aa[(q) >> 1].x)
+#define rb_(q) (((q) & 1) ? ab[(q) >> 1].y : ab[(q) >> 1].x)
+      if (diag) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) ab[q] = aa[q];
+      } else {
+        fz_rows_from_state<false>(rk, static_cast<const double2*>(nullptr), x01.x, x01.y, x2v.x, make_double2(0.0, 0.0), live, ab);
+      }
+      // T = B_a V^-1 B_b^T with B = minus the camera-centre columns of A (the two signs cancel)
+      const double h00 = ra_(4) * i00 + ra_(5) * i01 + ra_(6) * i02;
+      const double h01 = ra_(4) * i01 + ra_(5) * i11 + ra_(6) * i12;
+      const double h02 = ra_(4) * i02 + ra_(5) * i12 + ra_(6) * i22;
+      const double h10 = ra_(11) * i00 + ra_(12) * i01 + ra_(13) * i02;
+      const double h11 = ra_(11) * i01 + ra_(12) * i11 + ra_(13) * i12;
+      const double h12 = ra_(11) * i02 + ra_(12) * i12 + ra_(13) * i22;
+      double t00 = h00 * rb_(4) + h01 * rb_(5) + h02 * rb_(6), t01 = h00 * rb_(11) + h01 * rb_(12) + h02 * rb_(13);
+      double t10 = h10 * rb_(4) + h11 * rb_(5) + h12 * rb_(6), t11 = h10 * rb_(11) + h11 * rb_(12) + h12 * rb_(13);
+      if (diag && live) {
+        t00 -= 1.0;
+        t11 -= 1.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 14; ++q) o[q] = ra_(q);
+#pragma unroll
+      for (int c = 0; c < 7; ++c) {
+        o[14 + c] = t00 * rb_(c) + t01 * rb_(7 + c);
+        o[21 + c] = t10 * rb_(c) + t11 * rb_(7 + c);
+      }
+#undef ra_
+#undef rb_
+#else
+#pragma unroll
+      for (int q = 0; q < 28; ++q) o[q] = x01.x + v5 + rj[0].x + rk[0].y;
+#endif
+      o[28] = gv.x;
+      o[29] = gv.y;
+      o[30] = qs;
+      o[31] = 0.5;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- phase 2: the step's entries in order (two interleaved sums: even and odd entries); eight
+    // entries' operands are fetched before the first of them is used ----
+    {
+#ifndef SFMBA_PAIR_SKIP_P2
+      const int cnt = end - i0 < 64 ? end - i0 : 64;
+#else
+      const int cnt = 1;
+#endif
+      const double* q = img;
+      int e = 0;
+      for (; e + 8 <= cnt; e += 8, q += 8 * kPairStateRec) {
+        double a0[8], a1[8], p0[8], p1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a0[u] = q[u * kPairStateRec + oa0];
+          a1[u] = q[u * kPairStateRec + oa1];
+          p0[u] = q[u * kPairStateRec + op0];
+          p1[u] = q[u * kPairStateRec + op1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+          acc0 = fma(a1[u], p1[u], fma(a0[u], p0[u], acc0));
+          acc1 = fma(a1[u + 1], p1[u + 1], fma(a0[u + 1], p0[u + 1], acc1));
+        }
+      }
+      for (; e + 2 <= cnt; e += 2, q += 2 * kPairStateRec) {
+        acc0 = fma(q[oa1], q[op1], fma(q[oa0], q[op0], acc0));
+        acc1 = fma(q[kPairStateRec + oa1], q[kPairStateRec + op1], fma(q[kPairStateRec + oa0], q[kPairStateRec + op0], acc1));
+      }
+      if (e < cnt) acc0 = fma(q[oa1], q[op1], fma(q[oa0], q[op0], acc0));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!counts) return;
+  const double v = acc0 + acc1;
+  const int part = pit_part[item];
+  const int64_t ld = 7 * (int64_t)m;
+  if (part >= 0) {
+    spart[(int64_t)part * kPairPartStride + lane] = v;
+    return;
+  }
+  if (lane == 56) {
+    if (ssq_out) ssq_out[bj] = v;
+  } else if (lane >= 49) {
+    S[ld * ld + 7 * bj + (lane - 49)] = v;
+    if (e_out) e_out[7 * bj + (lane - 49)] = v;
+  } else {
+    const int r = lane / 7, c = lane - 7 * r;
+    if (diag)
+      S[(7 * (int64_t)bj + r) * ld + 7 * bk + c] = (r == c ? mu_u : 0.0) - v;
+    else
+      S[(7 * (int64_t)bk + c) * ld + 7 * bj + r] = -v;
   }
 }
 
@@ -1358,6 +1551,16 @@ int launch_jacobian(const double* blk, const double* P, const double* X, const i
   return check_launch("k_jacobian");
 }
 
+// SFM_BA_PAIR_STATE=0: the far points of a plan go through the camera-pair kernel that gathers rows of A
+// and couplings (comparison runs)
+static bool pair_state_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("SFM_BA_PAIR_STATE");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, const double* xt,
                     const double* xp, const double* w, double mu, double mu_u, double* S, double* e,
                     double* U, double* eps_a, double* Vinv, double* eps_b, double* cam_red,
@@ -1379,7 +1582,8 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
     {
     ProfScope ps(KID_POINT, st);
     hipLaunchKernelGGL(k_point, dim3(p->n_groups), dim3(256), 0, st, static_cast<const int32_t*>(nullptr), p->d_grp_pt,
-                       p->d_pt_ptr, p->d_perm, p->d_tp_ptr, p->d_pair_entry, A, B, xt, xp, w, mu, fold_u, Vinv, eps_b, g, qsq, T);
+                       p->d_pt_ptr, p->d_perm, p->d_tp_ptr, p->d_pair_entry, A, B, xt, xp, w, mu, fold_u, Vinv, eps_b, g, qsq, T,
+                       static_cast<const double*>(nullptr), static_cast<double*>(nullptr));
   }
     int rc = check_launch("k_point");
     if (rc) return rc;
@@ -1432,19 +1636,24 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
 // of A_j^T T A_k - which on the diagonal hold sum Y W^T - U_j - and of A^T g, left in the workspace for the
 // finishing kernel of the larger plan.  The point block is taken from A; no weights.
 int launch_assemble_parts(const sfm_ba_plan* p, const int32_t* pt_map, const double* A, const double* xt,
-                          const double* xp, double mu, double* Vinv, double* eps_b, void* ws, hipStream_t st) {
+                          const double* xp, double mu, double* Vinv, double* eps_b, void* ws, const double* blk,
+                          const double* X, hipStream_t st) {
   if (!p->force_parts) return SFM_BA_EINVAL;
   char* base = static_cast<char*>(ws);
   double* g = reinterpret_cast<double*>(base + p->ws_g);
   double* T = reinterpret_cast<double*>(base + p->ws_T);
   double* qsq = reinterpret_cast<double*>(base + p->ws_q);
   double* spart = reinterpret_cast<double*>(base + p->ws_spart);
+  double* prec = reinterpret_cast<double*>(base + p->ws_prec);
+  const bool from_state = blk && X && pair_state_enabled();
   if (p->n_groups > 0) {
     {
       ProfScope ps(KID_POINT, st);
       hipLaunchKernelGGL(k_point, dim3(p->n_groups), dim3(256), 0, st, pt_map, p->d_grp_pt, p->d_pt_ptr, p->d_perm,
                          p->d_tp_ptr, p->d_pair_entry, A, static_cast<const double*>(nullptr), xt, xp,
-                         static_cast<const double*>(nullptr), mu, 1, Vinv, eps_b, g, qsq, T);
+                         static_cast<const double*>(nullptr), mu, 1, Vinv, eps_b, g, qsq,
+                         from_state ? static_cast<double*>(nullptr) : T, from_state ? X : static_cast<const double*>(nullptr),
+                         from_state ? prec : static_cast<double*>(nullptr));
     }
     const int rc = check_launch("k_point");
     if (rc) return rc;
@@ -1452,13 +1661,63 @@ int launch_assemble_parts(const sfm_ba_plan* p, const int32_t* pt_map, const dou
   if (p->n_pair_items > 0) {
     {
       ProfScope ps(KID_PAIR_BLOCKS, st);
-      hipLaunchKernelGGL(k_pair_blocks, dim3(p->n_pair_items), dim3(64), 0, st, p->n_pair_items, p->d_pit_blk, p->d_pit_beg,
-                         p->d_pit_end, p->d_pit_part, p->d_blk_j, p->d_blk_k, p->d_entries, A, g,
-                         (unsigned)(p->ws_T - p->ws_g), (unsigned)(p->ws_q - p->ws_g), 1,
-                         static_cast<const double*>(nullptr), p->d_cam_item_ptr, 0.0, p->m, static_cast<double*>(nullptr),
-                         static_cast<double*>(nullptr), static_cast<double*>(nullptr), spart);
+      if (from_state)
+        hipLaunchKernelGGL(k_pair_state, dim3(p->n_pair_items), dim3(64), 0, st, p->n_pair_items, p->d_pit_blk, p->d_pit_beg,
+                           p->d_pit_end, p->d_pit_part, p->d_blk_j, p->d_blk_k, p->d_entries, p->d_ent_pt, blk, prec, g, qsq, 0.0,
+                           p->m, static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr),
+                           spart);
+      else
+        hipLaunchKernelGGL(k_pair_blocks, dim3(p->n_pair_items), dim3(64), 0, st, p->n_pair_items, p->d_pit_blk, p->d_pit_beg,
+                           p->d_pit_end, p->d_pit_part, p->d_blk_j, p->d_blk_k, p->d_entries, A, g,
+                           (unsigned)(p->ws_T - p->ws_g), (unsigned)(p->ws_q - p->ws_g), 1,
+                           static_cast<const double*>(nullptr), p->d_cam_item_ptr, 0.0, p->m, static_cast<double*>(nullptr),
+                           static_cast<double*>(nullptr), static_cast<double*>(nullptr), spart);
     }
-    return check_launch("k_pair_blocks");
+    return check_launch(from_state ? "k_pair_state" : "k_pair_blocks");
+  }
+  return SFM_BA_OK;
+}
+
+// The camera-pair path of a whole plan inside the loop.  A: the rows sfm_ba_jacobian wrote from this state
+// (the per-point stage takes the point blocks from them, the back-substitution reads them afterwards); the
+// camera-pair products are formed from the state.  Writes the lower triangle of S, row 7m, e, V^-1, eps_b
+// and (ssq) the per-camera sums of squared residuals.
+int launch_assemble_pairs_state(const sfm_ba_plan* p, const double* A, const double* blk, const double* X,
+                                const double* xt, const double* xp, double mu, double mu_u, double* S, double* e,
+                                double* Vinv, double* eps_b, double* ssq, void* ws, hipStream_t st) {
+  char* base = static_cast<char*>(ws);
+  double* g = reinterpret_cast<double*>(base + p->ws_g);
+  double* qsq = reinterpret_cast<double*>(base + p->ws_q);
+  double* spart = reinterpret_cast<double*>(base + p->ws_spart);
+  double* prec = reinterpret_cast<double*>(base + p->ws_prec);
+  if (p->n_groups > 0) {
+    {
+      ProfScope ps(KID_POINT, st);
+      hipLaunchKernelGGL(k_point, dim3(p->n_groups), dim3(256), 0, st, static_cast<const int32_t*>(nullptr), p->d_grp_pt,
+                         p->d_pt_ptr, p->d_perm, p->d_tp_ptr, p->d_pair_entry, A, static_cast<const double*>(nullptr), xt, xp,
+                         static_cast<const double*>(nullptr), mu, 1, Vinv, eps_b, g, qsq, static_cast<double*>(nullptr), X, prec);
+    }
+    const int rc = check_launch("k_point");
+    if (rc) return rc;
+  }
+  if (p->n_pair_items > 0) {
+    {
+      ProfScope ps(KID_PAIR_BLOCKS, st);
+      hipLaunchKernelGGL(k_pair_state, dim3(p->n_pair_items), dim3(64), 0, st, p->n_pair_items, p->d_pit_blk, p->d_pit_beg,
+                         p->d_pit_end, p->d_pit_part, p->d_blk_j, p->d_blk_k, p->d_entries, p->d_ent_pt, blk, prec, g, qsq, mu_u,
+                         p->m, S, e, ssq, spart);
+    }
+    int rc = check_launch("k_pair_state");
+    if (rc) return rc;
+    if (p->n_multi > 0) {
+      {
+        ProfScope ps(KID_PAIR_FINISH, st);
+        hipLaunchKernelGGL(k_pair_finish, dim3(p->n_multi), dim3(64), 0, st, p->d_mb_blk, p->d_mb_part, p->d_mb_cnt, p->d_blk_j,
+                           p->d_blk_k, spart, static_cast<const double*>(nullptr), p->d_cam_item_ptr, mu_u, p->m, 1, S, e, ssq);
+      }
+      rc = check_launch("k_pair_finish");
+      if (rc) return rc;
+    }
   }
   return SFM_BA_OK;
 }

@@ -51,6 +51,8 @@ void plan_set_workspace(sfm_ba_plan* p) {
     f.ws_key = off;
     off = align256(off + (int64_t)f.n_keys * (f.slots ? fz_part_stride(f.slots) : 0) * (int64_t)sizeof(double));
   }
+  p->ws_prec = off;  // per point: position and V^-1, for the camera-pair kernel that forms its rows itself
+  off = align256(off + (int64_t)std::max(p->n, 1) * kPointRec * (int64_t)sizeof(double));
   p->ws_fzero = off;  // a row of zeros
   off = align256(off + 256);
   // far points: their rows of A, observed and predicted pixels in the far plan's observation order,
@@ -76,7 +78,7 @@ extern "C" void sfm_ba_plan_destroy(sfm_ba_plan* p) {
   if (!p) return;
   void* ptrs[] = {p->d_pt_ptr,   p->d_perm,     p->d_slot_cam, p->d_tp_ptr,  p->d_grp_pt,  p->d_cam_obs, p->d_pair_entry,
                   p->d_item_cam, p->d_item_beg, p->d_item_end, p->d_cam_item_ptr, p->d_blk_j, p->d_blk_k,
-                  p->d_entries,  p->d_pit_blk,  p->d_pit_beg,  p->d_pit_end, p->d_pit_part, p->d_mb_blk,
+                  p->d_entries,  p->d_ent_pt,   p->d_pit_blk,  p->d_pit_beg,  p->d_pit_end, p->d_pit_part, p->d_mb_blk,
                   p->d_mb_part,  p->d_mb_cnt,   p->d_fb_ptr,   p->d_fb_ent,
                   p->d_fb_far_part, p->d_fb_far_cnt, p->d_far_pt, p->d_far_obs, p->d_far_cam, p->d_far_lpt, p->d_far_gpt};
   for (void* q : ptrs)
@@ -464,6 +466,12 @@ int build_host(const int32_t* cam_idx, const int32_t* pt_idx, int64_t N, int32_t
   up(blk_j, &p->d_blk_j);
   up(blk_k, &p->d_blk_k);
   up(entries, &p->d_entries);
+  {
+    // point of every entry (both of its observations belong to it)
+    std::vector<int32_t> ent_pt((size_t)p->n_entries);
+    for (int64_t e = 0; e < p->n_entries; ++e) ent_pt[(size_t)e] = pt_idx[entries[(size_t)e].row_a / 112];
+    up(ent_pt, &p->d_ent_pt);
+  }
   up(pit_blk, &p->d_pit_blk);
   up(pit_beg, &p->d_pit_beg);
   up(pit_end, &p->d_pit_end);
@@ -574,6 +582,7 @@ extern "C" int sfm_ba_plan_read(const sfm_ba_plan* p, int field, void* h_dst, in
     case 35: src = p->d_far_cam; count = p->n_far_obs; break;
     case 36: src = p->d_far_lpt; count = p->n_far_obs; break;
     case 37: src = p->d_far_gpt; count = p->n_far_obs; break;
+    case 38: src = p->d_ent_pt; count = p->n_entries; break;
     default: return SFM_BA_EINVAL;
   }
   *bytes_out = count * width;

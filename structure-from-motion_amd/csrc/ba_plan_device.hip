@@ -222,12 +222,15 @@ __global__ void k_pair_keys(const int32_t* __restrict__ pt_ptr, const int32_t* _
 }
 
 __global__ void k_place_entries(const int32_t* __restrict__ sorted_slot, const PairEntry* __restrict__ rec, int64_t E,
-                                PairEntry* __restrict__ entries, int32_t* __restrict__ pair_entry) {
+                                const int32_t* __restrict__ pt, PairEntry* __restrict__ entries,
+                                int32_t* __restrict__ pair_entry, int32_t* __restrict__ ent_pt) {
   const int64_t pos = (int64_t)blockIdx.x * kT + threadIdx.x;
   if (pos >= E) return;
   const int32_t ts = sorted_slot[pos];
-  entries[pos] = rec[ts];
+  const PairEntry en = rec[ts];
+  entries[pos] = en;
   pair_entry[ts] = (int32_t)pos;
+  ent_pt[pos] = pt[en.row_a / 112u];  // (both observations of an entry belong to one point)
 }
 
 // first entry of every block from the sorted keys (every block id occurs: a block exists because a
@@ -707,7 +710,8 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
   SFMBA_TRY(keep(&p->d_pair_entry, pairs, &bytes));
   // the camera-pair kernel fetches whole steps: valid (zero) records behind the last entry
   SFMBA_HIP(hipMemsetAsync(p->d_entries + pairs, 0, sizeof(PairEntry) * kPairPad, st));
-  k_place_entries<<<blocks_for(pairs), kT, 0, st>>>(pval_sorted, rec, pairs, p->d_entries, p->d_pair_entry);
+  SFMBA_TRY(keep(&p->d_ent_pt, pairs, &bytes));
+  k_place_entries<<<blocks_for(pairs), kT, 0, st>>>(pval_sorted, rec, pairs, pt, p->d_entries, p->d_pair_entry, p->d_ent_pt);
   k_block_starts<<<blocks_for(pairs), kT, 0, st>>>(pkey_sorted, pairs, nb, blk_ptr);
 
   // ---- pair work items and the partial results of split blocks ----

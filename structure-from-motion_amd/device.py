@@ -47,7 +47,7 @@ class Plan:
               "item_end", "cam_item_ptr", "blk_j", "blk_k", "entries", "pit_blk", "pit_beg", "pit_end", "pit_part",
               "mb_blk", "mb_part", "mb_cnt", "run_pt0", "run_key", "slot_obs", "key_cam", "key_run", "rng_run", "fz_pt",
               "run_cam", "fb_ptr", "fb_ent", "fb_far_part", "fb_far_cnt", "far_pt", "far_obs", "far_cam", "far_lpt",
-              "far_gpt")
+              "far_gpt", "ent_pt")
     # the arrays of the fused assembly (21..28: one set per class of near points) and of the near / far split
     CLASS_FIELDS = FIELDS[21:29]
     FUSED_FIELDS = FIELDS[21:]
@@ -411,6 +411,26 @@ class DeviceProblem:
                 self._all_reduce(self.ssq)
             _lib.check(self.lib.sfm_ba_cost_finish(p(self.ssq), self.m, p(self.cost_buf), _stream()))
 
+    def assemble_pairs_state(self, mu, want_cost=False):
+        """Schur assembly of any plan inside the loop: ``self.A`` holds the rows the Jacobian kernel wrote
+        from the current state (the per-point stage and the back-substitution read them), and the
+        camera-pair products are formed from the state inside their kernel instead of being gathered.
+        ``want_cost`` as in ``assemble_state``."""
+        p = _lib.ptr
+        self._sys_fresh = False
+        mu_u = self._prepare_system(mu, self.band_sharded)
+        if want_cost and self.sharded:
+            self.ssq.zero_()
+        _lib.check(self.lib.sfm_ba_schur_assemble_pairs_state(
+            self.plan.handle, p(self.A), p(self.cam_blk), p(self.X), p(self.x_true), p(self.x_pred), float(mu),
+            float(mu_u), p(self.S), p(self.e), p(self.V_inv), p(self.eps_b), p(self.ssq) if want_cost else None,
+            p(self.workspace), _stream()))
+        self._exchange_system(mu, self.band_sharded)
+        if want_cost:
+            if self.sharded:
+                self._all_reduce(self.ssq)
+            _lib.check(self.lib.sfm_ba_cost_finish(p(self.ssq), self.m, p(self.cost_buf), _stream()))
+
     def back_substitute_state(self, update_points=False):
         """delta_b (and the point update) with the rows of A formed again from the state (the far
         points' rows are still in the workspace of the assembly)."""
@@ -517,6 +537,19 @@ class DeviceProblem:
             self.back_substitute_state(update_points=True)
             self.update_cameras(prepare_next=True)
             self.assemble_state(mu, want_cost=True)
+            self._sys_fresh, self._sys_mu = True, mu
+            return
+        if self._want_state and mu > 0:
+            # any other plan: the same shape of iteration on the camera-pair kernels, with the products
+            # of a camera pair formed from the state and the cost out of the diagonal blocks
+            if not (self._sys_fresh and self._sys_mu == mu):
+                self.jacobian(want_B=False)
+                self.assemble_pairs_state(mu, want_cost=True)
+            self.solve()
+            self.back_substitute(update_points=True, B=False)
+            self.update_cameras(prepare_next=True)
+            self.jacobian(want_B=False)
+            self.assemble_pairs_state(mu, want_cost=True)
             self._sys_fresh, self._sys_mu = True, mu
             return
         else:
