@@ -278,11 +278,9 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
 // the fused path of launch_assemble (plan with runs, no weights, no by-products, B taken from A)
 int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* xt, const double* xp, double mu,
                           double mu_u, double* S, double* e, double* Vinv, double* eps_b, void* ws, hipStream_t st);
-// the camera-pair path of a far plan (see sfm_ba_plan::far): partial results only, points renumbered by pt_map.
-// blk / X given: the camera-pair products are formed from the state (k_pair_state) instead of gathered rows of A
+// the camera-pair path of a far plan (see sfm_ba_plan::far): partial results only, points renumbered by pt_map
 int launch_assemble_parts(const sfm_ba_plan* p, const int32_t* pt_map, const double* A, const double* xt,
-                          const double* xp, double mu, double* Vinv, double* eps_b, void* ws, const double* blk,
-                          const double* X, hipStream_t st);
+                          const double* xp, double mu, double* Vinv, double* eps_b, void* ws, hipStream_t st);
 // the camera-pair path of a whole plan in the loop: A as sfm_ba_jacobian wrote it from this state (the per-point
 // stage and the back-substitution read it), camera-pair products formed from the state; S, e, the per-camera
 // squared residuals

@@ -769,12 +769,10 @@ static int launch_far_unobserved(const sfm_ba_plan* p, double mu, double* Vinv, 
 // The far points' share of the assembly: V^-1, eps_b of those points, g and T in the far plan's
 // workspace, and the partial results of its camera-pair blocks, which k_fused_finish adds into S.
 // A_far, xt_far, xp_far: rows of A and pixels in the far plan's observation order.
-// blk / X given: the camera-pair products of the far points are formed from the state (k_pair_state)
 static int launch_far_assemble(const sfm_ba_plan* p, const double* A_far, const double* xt_far, const double* xp_far,
-                               double mu, double* Vinv, double* eps_b, char* ws, const double* blk, const double* X,
-                               hipStream_t st) {
+                               double mu, double* Vinv, double* eps_b, char* ws, hipStream_t st) {
   if (!p->far) return SFM_BA_OK;
-  return launch_assemble_parts(p->far, p->d_far_pt, A_far, xt_far, xp_far, mu, Vinv, eps_b, ws + p->ws_far, blk, X, st);
+  return launch_assemble_parts(p->far, p->d_far_pt, A_far, xt_far, xp_far, mu, Vinv, eps_b, ws + p->ws_far, st);
 }
 
 static const double* far_partials(const sfm_ba_plan* p, const char* ws) {
@@ -811,7 +809,7 @@ int launch_assemble_state(const sfm_ba_plan* p, const double* blk, const double*
                        xt_far, xp_far);
     rc = check_launch_fz("k_far_gather");
     if (rc) return rc;
-    rc = launch_far_assemble(p, A_far, xt_far, xp_far, mu, Vinv, eps_b, base, blk, X, st);
+    rc = launch_far_assemble(p, A_far, xt_far, xp_far, mu, Vinv, eps_b, base, st);
     if (rc) return rc;
   } else {
     const int rc = launch_far_unobserved(p, mu, Vinv, eps_b, nullptr, st);
@@ -891,7 +889,7 @@ int launch_assemble_fused(const sfm_ba_plan* p, const double* A, const double* x
                        p->n_far_obs, A, xt, xp, A_far, xt_far, xp_far);
     int rc = check_launch_fz("k_far_gather");
     if (rc) return rc;
-    rc = launch_far_assemble(p, A_far, xt_far, xp_far, mu, Vinv, eps_b, base, nullptr, nullptr, st);
+    rc = launch_far_assemble(p, A_far, xt_far, xp_far, mu, Vinv, eps_b, base, st);
     if (rc) return rc;
   } else {
     const int rc = launch_far_unobserved(p, mu, Vinv, eps_b, nullptr, st);

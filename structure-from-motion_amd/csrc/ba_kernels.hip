@@ -1033,7 +1033,6 @@ __global__ __launch_bounds__(64, 3) void k_pair_state(
         qs = live ? ql : 0.0;
       }
       double* o = img + kPairStateRec * lane;
-#ifndef SFMBA_PAIR_SKIP_P1
       const double i00 = x2v.y, i01 = v12.x, i02 = v12.y, i11 = v34.x, i12 = v34.y, i22 = v5;
       double2 aa[9], ab[9];
       fz_rows_from_state<false>(rj, static_cast<const double2*>(nullptr), x01.x, x01.y, x2v.x, make_double2(0.0, 0.0), live, aa);
@@ -1067,10 +1066,6 @@ __global__ __launch_bounds__(64, 3) void k_pair_state(
       }
 #undef ra_
 #undef rb_
-#else
-#pragma unroll
-      for (int q = 0; q < 28; ++q) o[q] = x01.x + v5 + rj[0].x + rk[0].y;
-#endif
       o[28] = gv.x;
       o[29] = gv.y;
       o[30] = qs;
@@ -1082,11 +1077,7 @@ __global__ __launch_bounds__(64, 3) void k_pair_state(
     // ---- phase 2: the step's entries in order (two interleaved sums: even and odd entries); eight
     // entries' operands are fetched before the first of them is used ----
     {
-#ifndef SFMBA_PAIR_SKIP_P2
       const int cnt = end - i0 < 64 ? end - i0 : 64;
-#else
-      const int cnt = 1;
-#endif
       const double* q = img;
       int e = 0;
       for (; e + 8 <= cnt; e += 8, q += 8 * kPairStateRec) {
@@ -1551,16 +1542,6 @@ int launch_jacobian(const double* blk, const double* P, const double* X, const i
   return check_launch("k_jacobian");
 }
 
-// SFM_BA_PAIR_STATE=0: the far points of a plan go through the camera-pair kernel that gathers rows of A
-// and couplings (comparison runs)
-static bool pair_state_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("SFM_BA_PAIR_STATE");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
-
 int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, const double* xt,
                     const double* xp, const double* w, double mu, double mu_u, double* S, double* e,
                     double* U, double* eps_a, double* Vinv, double* eps_b, double* cam_red,
@@ -1636,24 +1617,23 @@ int launch_assemble(const sfm_ba_plan* p, const double* A, const double* B, cons
 // of A_j^T T A_k - which on the diagonal hold sum Y W^T - U_j - and of A^T g, left in the workspace for the
 // finishing kernel of the larger plan.  The point block is taken from A; no weights.
 int launch_assemble_parts(const sfm_ba_plan* p, const int32_t* pt_map, const double* A, const double* xt,
-                          const double* xp, double mu, double* Vinv, double* eps_b, void* ws, const double* blk,
-                          const double* X, hipStream_t st) {
+                          const double* xp, double mu, double* Vinv, double* eps_b, void* ws, hipStream_t st) {
+  // (the far points are long tracks: the gathering kernel fetches their rows of A again and again out of the
+  // L2, and is the faster one for them - 88 us against 142 for k_pair_state at 500 cameras x 300 k points,
+  // tracks visibility)
   if (!p->force_parts) return SFM_BA_EINVAL;
   char* base = static_cast<char*>(ws);
   double* g = reinterpret_cast<double*>(base + p->ws_g);
   double* T = reinterpret_cast<double*>(base + p->ws_T);
   double* qsq = reinterpret_cast<double*>(base + p->ws_q);
   double* spart = reinterpret_cast<double*>(base + p->ws_spart);
-  double* prec = reinterpret_cast<double*>(base + p->ws_prec);
-  const bool from_state = blk && X && pair_state_enabled();
   if (p->n_groups > 0) {
     {
       ProfScope ps(KID_POINT, st);
       hipLaunchKernelGGL(k_point, dim3(p->n_groups), dim3(256), 0, st, pt_map, p->d_grp_pt, p->d_pt_ptr, p->d_perm,
                          p->d_tp_ptr, p->d_pair_entry, A, static_cast<const double*>(nullptr), xt, xp,
-                         static_cast<const double*>(nullptr), mu, 1, Vinv, eps_b, g, qsq,
-                         from_state ? static_cast<double*>(nullptr) : T, from_state ? X : static_cast<const double*>(nullptr),
-                         from_state ? prec : static_cast<double*>(nullptr));
+                         static_cast<const double*>(nullptr), mu, 1, Vinv, eps_b, g, qsq, T,
+                         static_cast<const double*>(nullptr), static_cast<double*>(nullptr));
     }
     const int rc = check_launch("k_point");
     if (rc) return rc;
@@ -1661,19 +1641,13 @@ int launch_assemble_parts(const sfm_ba_plan* p, const int32_t* pt_map, const dou
   if (p->n_pair_items > 0) {
     {
       ProfScope ps(KID_PAIR_BLOCKS, st);
-      if (from_state)
-        hipLaunchKernelGGL(k_pair_state, dim3(p->n_pair_items), dim3(64), 0, st, p->n_pair_items, p->d_pit_blk, p->d_pit_beg,
-                           p->d_pit_end, p->d_pit_part, p->d_blk_j, p->d_blk_k, p->d_entries, p->d_ent_pt, blk, prec, g, qsq, 0.0,
-                           p->m, static_cast<double*>(nullptr), static_cast<double*>(nullptr), static_cast<double*>(nullptr),
-                           spart);
-      else
-        hipLaunchKernelGGL(k_pair_blocks, dim3(p->n_pair_items), dim3(64), 0, st, p->n_pair_items, p->d_pit_blk, p->d_pit_beg,
-                           p->d_pit_end, p->d_pit_part, p->d_blk_j, p->d_blk_k, p->d_entries, A, g,
-                           (unsigned)(p->ws_T - p->ws_g), (unsigned)(p->ws_q - p->ws_g), 1,
-                           static_cast<const double*>(nullptr), p->d_cam_item_ptr, 0.0, p->m, static_cast<double*>(nullptr),
-                           static_cast<double*>(nullptr), static_cast<double*>(nullptr), spart);
+      hipLaunchKernelGGL(k_pair_blocks, dim3(p->n_pair_items), dim3(64), 0, st, p->n_pair_items, p->d_pit_blk, p->d_pit_beg,
+                         p->d_pit_end, p->d_pit_part, p->d_blk_j, p->d_blk_k, p->d_entries, A, g,
+                         (unsigned)(p->ws_T - p->ws_g), (unsigned)(p->ws_q - p->ws_g), 1,
+                         static_cast<const double*>(nullptr), p->d_cam_item_ptr, 0.0, p->m, static_cast<double*>(nullptr),
+                         static_cast<double*>(nullptr), static_cast<double*>(nullptr), spart);
     }
-    return check_launch(from_state ? "k_pair_state" : "k_pair_blocks");
+    return check_launch("k_pair_blocks");
   }
   return SFM_BA_OK;
 }
