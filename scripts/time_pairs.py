@@ -1,10 +1,11 @@
 """Time of the camera-pair assembly from the state alone (no solve): python scripts/time_pairs.py [visibility] [workload]"""
+import os
 import sys
 
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sfm_amd  # noqa: F401
 from sfm_amd import _lib, synthetic
 from sfm_amd.device import DeviceProblem
