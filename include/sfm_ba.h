@@ -398,7 +398,10 @@ int sfm_ba_cost(const sfm_ba_plan* plan, const double* d_P, const double* d_X, c
  * ends), and the call performs no allocation of any kind (no timing events either: it is never part
  * of the per-kernel profile).  Limit: SFM_BA_COST_NOALLOC_MAX_ITEMS per-camera work items, i.e. sum over
  * cameras of ceil(observations of the camera / 1024); a larger plan is refused with SFM_BA_ETOOBIG.
- * All calls on one GPU share the array: calls that overlap on one GPU (different streams) race. */
+ * All calls on one GPU share the array: calls that overlap on one GPU (different streams) race.
+ * The array's address on a device is looked up (hipGetSymbolAddress, once per device) when a plan is
+ * created on that device, so the call itself issues its two launches and nothing else and may be
+ * captured into a graph; with a plan created on another device the first call does the lookup. */
 #define SFM_BA_COST_NOALLOC_MAX_ITEMS 65536
 int sfm_ba_cost_noalloc(const sfm_ba_plan* plan, const double* d_P, const double* d_X, const int32_t* d_cam_idx,
                         const int32_t* d_pt_idx, const double* d_x_true, double* d_cam_ssq, double* d_cost,

@@ -1872,6 +1872,18 @@ static int cost_scratch_for_current_device(double** out) {
   return SFM_BA_OK;
 }
 
+}  // namespace sfmba
+
+// Called when a plan is created (weakly bound there): the address of the array on the plan's device is
+// looked up then, so that sfm_ba_cost_noalloc itself - which may run under stream capture - finds it
+// and makes no runtime call besides its launches.
+extern "C" int sfmba_cost_scratch_warm(void) {
+  double* ptr = nullptr;
+  return sfmba::cost_scratch_for_current_device(&ptr);
+}
+
+namespace sfmba {
+
 int launch_cost_noalloc(const sfm_ba_plan* p, const double* P, const double* X, const int32_t* cam, const int32_t* pt,
                         const double* xt, double* ssq, double* cost, hipStream_t st) {
   if (p->n_items > kCostStaticItems) return SFM_BA_ETOOBIG;

@@ -72,6 +72,9 @@ void plan_set_workspace(sfm_ba_plan* p) {
 
 using namespace sfmba;
 
+// defined in ba_kernels.hip; absent from host-only builds of this file (tests/native/plan_check.cpp)
+extern "C" int sfmba_cost_scratch_warm(void) __attribute__((weak));
+
 extern "C" const char* sfm_ba_last_hip_error(void) { return sfmba::last_hip_error(); }
 
 extern "C" void sfm_ba_plan_destroy(sfm_ba_plan* p) {
@@ -515,7 +518,10 @@ int build_host(const int32_t* cam_idx, const int32_t* pt_idx, int64_t N, int32_t
 
 extern "C" int sfm_ba_plan_create(const int32_t* cam_idx, const int32_t* pt_idx, int64_t N, int32_t m_hint,
                                   int32_t n_hint, int check, sfm_ba_plan** out) {
-  return build_host(cam_idx, pt_idx, N, m_hint, n_hint, check, 0, nullptr, out);
+  const int rc = build_host(cam_idx, pt_idx, N, m_hint, n_hint, check, 0, nullptr, out);
+  // (the array sfm_ba_cost_noalloc uses: its address on this device is looked up now, not under a capture)
+  if (rc == SFM_BA_OK && sfmba_cost_scratch_warm) (void)sfmba_cost_scratch_warm();
+  return rc;
 }
 
 extern "C" const sfm_ba_plan* sfm_ba_plan_far(const sfm_ba_plan* p) { return p ? p->far : nullptr; }

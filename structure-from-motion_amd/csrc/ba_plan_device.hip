@@ -933,6 +933,8 @@ int build(const int32_t* cam, const int32_t* pt, int64_t N, int32_t m_hint, int3
 }  // namespace
 }  // namespace sfmba
 
+extern "C" int sfmba_cost_scratch_warm(void);  // ba_kernels.hip
+
 extern "C" int sfm_ba_plan_create_device(const int32_t* d_cam_idx, const int32_t* d_pt_idx, int64_t n_obs,
                                          int32_t n_cams_hint, int32_t n_pts_hint, int check, void* stream,
                                          sfm_ba_plan** out_plan) {
@@ -946,6 +948,7 @@ extern "C" int sfm_ba_plan_create_device(const int32_t* d_cam_idx, const int32_t
     sfm_ba_plan_destroy(p);
     return rc;
   }
+  (void)sfmba_cost_scratch_warm();  // (the array sfm_ba_cost_noalloc uses: looked up now, not under a capture)
   *out_plan = p;
   return SFM_BA_OK;
 }

@@ -42,3 +42,44 @@ def test_cost_without_allocation_matches_cost():
         # and once more on the same problem: the array keeps the last call's contents, nothing depends on them
         _, _, ssq_c, cost_c = _both(prob)
         assert np.array_equal(ssq_b, ssq_c) and cost_c == cost_b
+
+
+def test_no_allocation_and_capture():
+    """The call leaves the device's free memory as it was, and can be captured into a graph (the array's
+    address was looked up when the plan was created): the replay writes the same bits."""
+    import torch
+
+    from sfm_amd import _lib, synthetic
+    from sfm_amd.device import DeviceProblem
+
+    p = synthetic.make_problem(12, 4000, 5, visibility="banded", seed=8)
+    prob = DeviceProblem(p.K, p.R, p.T, p.X, p.cam_idx, p.pt_idx, p.x_true)
+    lib, ptr = _lib.load(), _lib.ptr
+    ssq_ref, cost_ref, _, _ = _both(prob)
+    ssq = torch.zeros_like(prob.ssq)
+    cost = torch.zeros((1,), dtype=torch.float64, device=prob.device)
+
+    def call():
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.sfm_ba_cost_noalloc(prob.plan.handle, ptr(prob.P), ptr(prob.X), ptr(prob.cam_idx), ptr(prob.pt_idx),
+                                           ptr(prob.x_true), ptr(ssq), ptr(cost), st))
+
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    reserved0 = torch.cuda.memory_reserved()
+    call()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0 and torch.cuda.memory_reserved() == reserved0
+    assert np.array_equal(ssq.cpu().numpy(), ssq_ref) and float(cost.item()) == cost_ref
+    ssq.zero_()
+    cost.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call()
+    torch.cuda.synchronize()
+    ssq.zero_()
+    cost.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(ssq.cpu().numpy(), ssq_ref) and float(cost.item()) == cost_ref
