@@ -32,9 +32,22 @@ def half_bandwidth(cam_pos, cam_idx, pt_idx, n_points: int) -> int:
     return int(7 * np.max(hi[seen] - lo[seen]) + 6)
 
 
+def _scipy():
+    """scipy.sparse, needed only by the camera orders of this module (``reorder=True``): a clear error
+    where it is missing, instead of an ImportError from the middle of a run."""
+    try:
+        import scipy.sparse  # noqa: F401
+        import scipy.sparse.csgraph  # noqa: F401
+        import scipy.sparse.linalg  # noqa: F401
+    except ImportError as exc:  # pragma: no cover - scipy is part of the image
+        raise ImportError("camera reordering (reorder=True, ordering.narrowest_order) needs scipy: "
+                          "scipy.sparse, scipy.sparse.csgraph, scipy.sparse.linalg.eigsh") from exc
+
+
 def covisibility_graph(cam_idx, pt_idx, n_cams: int, n_points: int):
     """Sparse (n_cams, n_cams) matrix with a non-zero (j, k) where cameras j and k share a point
     (the block pattern of S, diagonal included)."""
+    _scipy()
     from scipy.sparse import csr_matrix
 
     cam = np.asarray(cam_idx, dtype=np.int64)
@@ -81,9 +94,10 @@ def spectral_positions(cam_idx, pt_idx, n_cams: int, n_points: int, graph=None):
     by it interleaves the passes through the same place.  None when the graph is not connected,
     when it is so dense that no order gives a band (more than 128 neighbours per camera on
     average), or when the eigen-solver does not converge."""
+    _scipy()
     from scipy.sparse import diags
     from scipy.sparse.csgraph import connected_components
-    from scipy.sparse.linalg import eigsh
+    from scipy.sparse.linalg import ArpackError, ArpackNoConvergence, eigsh
 
     if n_cams < 3:
         return None
@@ -100,7 +114,8 @@ def spectral_positions(cam_idx, pt_idx, n_cams: int, n_points: int, graph=None):
     try:
         # shift-invert just below zero: the two smallest eigenvalues (0 and the one wanted)
         vals, vecs = eigsh(L, k=2, sigma=-1e-3, which="LM", v0=np.linspace(-1.0, 1.0, n_cams))
-    except Exception:
+    except (ArpackNoConvergence, ArpackError, RuntimeError):
+        # (no convergence, or a singular shifted matrix: the breadth-first order remains)
         return None
     f = vecs[:, np.argmax(vals)]
     order = np.argsort(f, kind="stable").astype(np.int64)
