@@ -51,7 +51,7 @@ def algorithmic_bytes(N, n, m, s_blocks, with_B=False):
 GROUPS = {
     "jacobian": ["k_jacobian"],
     "assembly": ["k_fused_state", "k_fused_runs", "k_fused_reduce", "k_fused_finish", "k_point", "k_camera_items",
-                 "k_camera_finish", "k_pair_blocks", "k_pair_finish"],
+                 "k_camera_finish", "k_pair_blocks", "k_pair_state", "k_pair_finish"],
     "back_substitution": ["k_back_substitute", "k_back_substitute_state"],
 }
 

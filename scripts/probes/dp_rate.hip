@@ -28,9 +28,31 @@ __global__ __launch_bounds__(1024) void k_rate(double* out, long long* cyc, doub
   out[l] = s;
   if (l == 0) cyc[0] = t1 - t0;
 }
+__global__ void k_long(double* out, long long* cyc) {
+  double a = 1.0 + 1e-3 * threadIdx.x, b = 1e-9, c = 0.0;
+  long long t0, t1;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  for (int rep = 0; rep < 400000; ++rep) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  out[threadIdx.x] = c;
+  if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
 int main() {
   double* d; long long* c;
   (void)hipMalloc(&d, 1024 * 8); (void)hipMalloc(&c, 64);
+  {
+    // what a tick of s_memtime is: a long kernel timed with events and with the counter
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    k_long<<<1, 64>>>(d, c); (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    k_long<<<1, 64>>>(d, c);
+    (void)hipEventRecord(e1);
+    (void)hipDeviceSynchronize();
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    long long ticks; (void)hipMemcpy(&ticks, c, 8, hipMemcpyDeviceToHost);
+    printf("s_memtime: %lld ticks in %.1f us of kernel time = %.1f ticks per us\n", ticks, ms * 1e3, ticks / (ms * 1e3));
+  }
   for (int waves : {1, 4, 8, 16}) {
     long long h0, h1;
     k_rate<0><<<1, 64 * waves>>>(d, c, 1e-3); (void)hipDeviceSynchronize();

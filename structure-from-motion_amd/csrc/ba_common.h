@@ -240,7 +240,7 @@ void plan_set_workspace(sfm_ba_plan* p);  // workspace section offsets from the 
 enum KernelId {
   KID_CAMERA_PREPARE = 0, KID_JACOBIAN, KID_POINT, KID_CAMERA_ITEMS, KID_CAMERA_FINISH, KID_PAIR_BLOCKS,
   KID_PAIR_FINISH, KID_SOLVE, KID_BACK, KID_UPDATE, KID_COST_ITEMS, KID_COST_FINISH, KID_CALC_W_Y, KID_TRIANGULATE, KID_FUSED_RUNS,
-  KID_FUSED_REDUCE, KID_FUSED_FINISH, KID_FUSED_STATE, KID_BACK_STATE, KID_COUNT
+  KID_FUSED_REDUCE, KID_FUSED_FINISH, KID_FUSED_STATE, KID_BACK_STATE, KID_PAIR_STATE, KID_COUNT
 };
 bool profiling_enabled();
 class ProfScope {

@@ -1676,7 +1676,7 @@ int launch_assemble_pairs_state(const sfm_ba_plan* p, const double* A, const dou
   }
   if (p->n_pair_items > 0) {
     {
-      ProfScope ps(KID_PAIR_BLOCKS, st);
+      ProfScope ps(KID_PAIR_STATE, st);
       hipLaunchKernelGGL(k_pair_state, dim3(p->n_pair_items), dim3(64), 0, st, p->n_pair_items, p->d_pit_blk, p->d_pit_beg,
                          p->d_pit_end, p->d_pit_part, p->d_blk_j, p->d_blk_k, p->d_entries, p->d_ent_pt, blk, prec, g, qsq, mu_u,
                          p->m, S, e, ssq, spart);

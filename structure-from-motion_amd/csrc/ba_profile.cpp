@@ -10,7 +10,8 @@ static const char* kNames[KID_COUNT] = {
     "k_camera_prepare", "k_jacobian",   "k_point",        "k_camera_items",  "k_camera_finish",
     "k_pair_blocks",    "k_pair_finish", "solve_reduced",  "k_back_substitute", "k_update_cameras",
     "k_cost_items",     "k_cost_finish", "k_calc_W_Y",     "k_triangulate",
-    "k_fused_runs",     "k_fused_reduce", "k_fused_finish", "k_fused_state", "k_back_substitute_state"};
+    "k_fused_runs",     "k_fused_reduce", "k_fused_finish", "k_fused_state", "k_back_substitute_state",
+    "k_pair_state"};
 
 struct Pending {
   int id;
