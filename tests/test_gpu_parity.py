@@ -412,7 +412,7 @@ def test_profile_selection_and_chained_events(ba):
         prob.iterate_async()
     torch.cuda.synchronize()
     _lib.profile_read()
-    sel = ["k_jacobian", "k_point", "k_pair_blocks", "k_back_substitute"]
+    sel = ["k_jacobian", "k_point", "k_pair_state", "k_back_substitute"]
     res = {}
     try:
         for chained in (False, True):
