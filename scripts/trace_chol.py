@@ -13,5 +13,5 @@ for r in last:
 steps = [o for o in out if o[0] == "k_chol_step"]
 print("launches", len(out), "total %.1f us" % ((out[-1][4] - out[0][3]) / 1e3), " steps: %d, sum %.1f us" % (len(steps), sum(o[2] for o in steps)))
 print("step durations (us), grid:", " ".join("%.1f/%d" % (o[2], o[1]) for o in steps))
-back = [o for o in out if o[0] == "k_chol_back"]
+back = [o for o in out if o[0].startswith("k_chol_back")]
 print("back: %d launches, sum %.1f us" % (len(back), sum(o[2] for o in back)))

@@ -4,16 +4,15 @@
 //
 // General path - blocked right-looking Cholesky, NB = 64, in place.  The right-hand side is carried
 // as row n, so the forward substitution L y = e happens as part of the panel solves; then a blocked
-// backward substitution L^T x = y.  Per panel:
-//   k_chol_diag   : first panel only: one workgroup factors and inverts the 64 x 64 diagonal block.
-//   k_chol_panel  : rows below the block (and the right-hand-side row) times inv(L_kk)^T   [MFMA]
-//                   All-zero 64-row tiles are flagged and skipped here and in the two kernels
-//                   below: S is block sparse whenever far-apart cameras share no point, and the
-//                   factor keeps those zeros outside the profile.
-//   k_chol_update : trailing lower-triangle tiles  A_ij -= P_i P_j^T                        [MFMA]
-//                   The workgroup of tile (0, 0) keeps its result on chip and factors it: the
-//                   diagonal work of the next panel needs no launch of its own.
-//   k_chol_back   : one step of L^T x = y per panel, last panel first.
+// backward substitution L^T x = y.
+//   k_chol_diag       : first panel only: one workgroup factors and inverts the 64 x 64 diagonal block.
+//   k_chol_step       : one launch per panel (ba_chol_step.inc): the rows below the block times
+//                       inv(L_kk)^T, the trailing update A_ij -= P_i P_j^T and the next diagonal
+//                       factorisation as roles of one kernel                               [MFMA]
+//                       All-zero 64-row tiles of the factor are flagged and skipped: S is block sparse
+//                       whenever far-apart cameras share no point, and the factor keeps those zeros
+//                       outside the profile.
+//   k_chol_back_group : four panels of L^T x = y per launch, last panel first.
 //
 // Narrow band (no non-zero further than 64 places from the diagonal; S is then block tridiagonal
 // in 64 x 64 blocks and is only read):
@@ -59,8 +58,8 @@ int64_t cholesky_workspace_bytes(int n) {
   int64_t wide = 0;
   for (int C = 2; C <= 4; C *= 2)
     if (wide_band_tiles(n, NB * C) == C) wide = wide_workspace_doubles(n, C) * (int64_t)sizeof(double);
-  // zero-tile flags, then the two tiles the look-ahead of the one-launch-per-panel path passes on
-  const int64_t flags = (np * (np + 2) + 64) * (int64_t)sizeof(int32_t) + 2 * NB * NB * (int64_t)sizeof(double) + 8;
+  // zero-tile flags, then the six tiles the look-ahead of the one-launch-per-panel path passes on
+  const int64_t flags = (np * (np + 2) + 64) * (int64_t)sizeof(int32_t) + 6 * NB * NB * (int64_t)sizeof(double) + 8;
   const int64_t tiles = np * NB * NB * (int64_t)sizeof(double);
   const int64_t general = (np * NB * NB + np * NB + 64) * (int64_t)sizeof(double) + (flags > tiles ? flags : tiles);
   const int64_t reduction = (4 * np * NB * NB + np * NB + 64) * (int64_t)sizeof(double);  // D, B, P_u, P_d, e per block
@@ -305,7 +304,7 @@ __device__ __forceinline__ void diag_core(double* __restrict__ L, double* __rest
   STAMP(19);
 }
 
-// first panel only: later diagonal blocks are factored by the workgroup of k_chol_update that
+// first panel only: later diagonal blocks are factored by the chain workgroup of k_chol_step that
 // produced them
 __global__ __launch_bounds__(256) void k_chol_diag(double* __restrict__ S, int n, int k0, int nb,
                                                    double* __restrict__ invL, int32_t* __restrict__ info) {
@@ -354,572 +353,97 @@ __device__ __forceinline__ void mfma_quadrant(const double* __restrict__ Pa, con
   }
 }
 
-// P = A_tile * invL^T for the 64-row tiles below the diagonal block; rows up to and including n
-// (the right-hand-side row).  grid.x = number of row tiles.
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ S, int n, int k0, int nb,
-                                                    const double* __restrict__ invL, int32_t* __restrict__ zflag) {
-  __shared__ double At[NB * LDT];
-  __shared__ double It[NB * LDT];
-  __shared__ int any_nz;
-  const int t = threadIdx.x;
-  const int row0 = k0 + nb + blockIdx.x * NB;
-  if (t == 0) any_nz = 0;
-  __syncthreads();
-  {
-    double va[NB * NB / 256], vi[NB * NB / 256];
-    bool nz = false;
-#pragma unroll
-    for (int it = 0; it < NB * NB / 256; ++it) {
-      const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
-      va[it] = (row0 + r <= n && c < nb) ? S[(int64_t)(row0 + r) * n + k0 + c] : 0.0;
-      vi[it] = (c <= r) ? invL[idx] : 0.0;  // only the lower triangle of the inverse is stored
-      nz |= va[it] != 0.0;
-    }
-    if (__any(nz) && (t & 63) == 0) any_nz = 1;
-#pragma unroll
-    for (int it = 0; it < NB * NB / 256; ++it) {
-      const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
-      At[r * LDT + c] = va[it];
-      It[r * LDT + c] = vi[it];
-    }
-  }
-  __syncthreads();
-  // an all-zero tile stays zero: record it so that the trailing update and the backward
-  // substitution skip it, and leave
-  if (t == 0) zflag[blockIdx.x] = any_nz ? 0 : 1;
-  if (!any_nz) return;
-  const int lane = t & 63, wave = t >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  d4_t acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
-  mfma_quadrant(At, It, wr, wc, lane, false, acc);
-  // result element (i, j, reg): row = 32 wr + 16 i + (lane >> 4) + 4 reg, col = 32 wc + 16 j + (lane & 15)
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int r = row0 + wr * 32 + i * 16 + (lane >> 4) + 4 * g;
-        const int c = wc * 32 + j * 16 + (lane & 15);
-        if (r <= n && c < nb) S[(int64_t)r * n + k0 + c] = acc[i][j][g];
-      }
-}
+#include "ba_chol_step.inc"
 
-// trailing update A_ij -= P_i P_j^T over lower-triangle tiles (ti >= tj); grid.x enumerates them.
-// The workgroup of tile (0, 0) - the next diagonal block - keeps its result on chip and goes
-// straight on to factor it (diag_core), so the next panel needs no separate diagonal launch and
-// that factorisation overlaps the rest of the update.
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ S, int n, int k0, int nb, int ntile,
-                                                     const int32_t* __restrict__ zflag,
-                                                     double* __restrict__ invL_next, int32_t* __restrict__ info) {
-  __shared__ double Pi[NB * LDT];
-  __shared__ double Pj[NB * LDT];
-  const int lin = blockIdx.x;
-  int ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
-  while ((int64_t)(ti + 1) * (ti + 2) / 2 <= lin) ++ti;
-  while ((int64_t)ti * (ti + 1) / 2 > lin) --ti;
-  const int tj = lin - ti * (ti + 1) / 2;
-  if (ti >= ntile) return;
-  const bool zero = (zflag[ti] | zflag[tj]) != 0;  // P_i or P_j is all zero: the tile does not change
-  const bool next_diag = lin == 0;
-  if (zero && !next_diag) return;
-  const int t = threadIdx.x;
-  const int base = k0 + nb;
-  const int row0 = base + ti * NB, col0 = base + tj * NB;
-  const int lane = t & 63, wave = t >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  // the tile's current values go straight into the accumulators
-  d4_t acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int r = row0 + wr * 32 + i * 16 + (lane >> 4) + 4 * g;
-        const int c = col0 + wc * 32 + j * 16 + (lane & 15);
-        acc[i][j][g] = (r <= n && c < n && c <= r) ? S[(int64_t)r * n + c] : 0.0;
-      }
-  if (!zero) {
-    double vi[NB * NB / 256], vj[NB * NB / 256];
-#pragma unroll
-    for (int it = 0; it < NB * NB / 256; ++it) {
-      const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
-      vi[it] = (c < nb && row0 + r <= n) ? S[(int64_t)(row0 + r) * n + k0 + c] : 0.0;
-      vj[it] = (c < nb && col0 + r < n) ? S[(int64_t)(col0 + r) * n + k0 + c] : 0.0;
-    }
-#pragma unroll
-    for (int it = 0; it < NB * NB / 256; ++it) {
-      const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
-      Pi[r * LDT + c] = vi[it];
-      Pj[r * LDT + c] = vj[it];
-    }
-    __syncthreads();
-    mfma_quadrant(Pi, Pj, wr, wc, lane, true, acc);
-  }
-  if (!next_diag) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int r = row0 + wr * 32 + i * 16 + (lane >> 4) + 4 * g;
-          const int c = col0 + wc * 32 + j * 16 + (lane & 15);
-          if (r <= n && c < n && c <= r) S[(int64_t)r * n + c] = acc[i][j][g];
-        }
-    return;
-  }
-  // tile (0, 0) = diagonal block of the next panel: park it in LDS (the operand buffers are free
-  // once every wave is past its MFMAs) and factor it
-  const int k0n = base, nbn = (n - base) < NB ? (n - base) : NB;
-  __syncthreads();
-  // (Pj becomes the inverse's buffer; every entry that is read is written first)
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int r = wr * 32 + i * 16 + (lane >> 4) + 4 * g;
-        const int c = wc * 32 + j * 16 + (lane & 15);
-        double v = (r == c) ? 1.0 : 0.0;  // identity padding past the matrix edge
-        if (r < nbn && c < nbn) v = (c <= r) ? acc[i][j][g] : 0.0;
-        Pi[r * LDT + c] = v;
-        // rows of this tile under a partial last block (the right-hand-side row) are not part of
-        // the diagonal block: they go back to memory as in every other tile
-        if (r >= nbn && base + r <= n && c < nbn) S[(int64_t)(base + r) * n + base + c] = acc[i][j][g];
-      }
-  diag_core(Pi, Pj, S, n, k0n, nbn, invL_next, info);
-}
-
-// ---- one launch per panel -------------------------------------------------------------------
-// The panel solve, the trailing update and the next diagonal factorisation of the general path in ONE
-// launch per panel, software-pipelined so that nothing in a launch depends on another workgroup of the
-// same launch.  State before launch k: inv(L_kk) and the factor's block columns q < k (P_iq, in place
-// in S) are final; a tile of block column j has received the panels q < lo(j, k) from the bulk
-// workgroups of earlier launches.  In launch k
-//   * workgroup 0 (the chain) brings tile (k+1, k) and the next diagonal block (k+1, k+1) up to date
-//     itself - the panels the bulk has not applied yet -, solves P_(k+1,k) = tile inv(L_kk)^T, takes
-//     P_(k+1,k) P_(k+1,k)^T off the diagonal block and factors it (diag_core): inv(L_(k+1,k+1)) for the
-//     next launch.  This chain of launches is the critical path: ~20 us a panel instead of a panel solve,
-//     an update and two launch gaps;
-//   * one workgroup per remaining row tile i > k + 1 applies the missing panels to tile (i, k) and
-//     solves it (P_ik, in place);
-//   * every `lag`-th launch, one workgroup per tile (i, j), j > k, (i, j) != (k+1, k+1), applies the
-//     last `lag` panels [k - lag, k) to it: with lag 2 the trailing matrix - which does not fit any
-//     cache from ~6 000 unknowns on - is read and written once per two panels.
-// A tile of block column j is therefore missing the panels [lag * floor((k-1)/lag), k) when its
-// launch k = j comes, and the chain's diagonal block the same plus panel k.
-// The right-hand side is row n of S: part of the last row tile, or (n a multiple of 64) a row tile of
-// its own.  When the last panel is narrower than 64 the row sits inside the last diagonal tile, whose
-// chain workgroup has brought it up to date: the last launch then solves it with nothing missing.
-
-// v = the 64 x 64 tile of S at (row0, col0): rows up to n (with_rhs) or n - 1, zero beyond
-__device__ __forceinline__ void chol_tile_regs(const double* __restrict__ S, int n, int row0, int col0, bool with_rhs,
-                                               int t, double (&v)[NB * NB / 256]) {
-  const int rmax = with_rhs ? n : n - 1;
-#pragma unroll
-  for (int it = 0; it < NB * NB / 256; ++it) {
-    const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
-    v[it] = (row0 + r <= rmax) ? S[(int64_t)(row0 + r) * n + col0 + c] : 0.0;
-  }
-}
-
-__device__ __forceinline__ void chol_regs_lds(const double (&v)[NB * NB / 256], double* __restrict__ l, int t) {
-#pragma unroll
-  for (int it = 0; it < NB * NB / 256; ++it) {
-    const int idx = t + 256 * it;
-    l[(idx / NB) * LDT + idx % NB] = v[it];
-  }
-}
-
-// accumulators <-> LDS tile (row-major, stride LDT)
-__device__ __forceinline__ void chol_acc_lds(const d4_t (&acc)[2][2], double* __restrict__ l, int wr, int wc, int lane) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        l[(wr * 32 + i * 16 + (lane >> 4) + 4 * g) * LDT + wc * 32 + j * 16 + (lane & 15)] = acc[i][j][g];
-}
-
-// acc = tile of S at (row0, col0), rows up to n, columns below `cend` (absolute); `lower`: entries above
-// the matrix diagonal read as zero
-__device__ __forceinline__ void chol_acc_load(const double* __restrict__ S, int n, int row0, int col0, int cend, bool lower,
-                                              int wr, int wc, int lane, d4_t (&acc)[2][2]) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int r = row0 + wr * 32 + i * 16 + (lane >> 4) + 4 * g;
-        const int c = col0 + wc * 32 + j * 16 + (lane & 15);
-        acc[i][j][g] = (r <= n && c < cend && (!lower || c <= r)) ? S[(int64_t)r * n + c] : 0.0;
-      }
-}
-
-__device__ __forceinline__ void chol_acc_store(double* __restrict__ S, int n, int row0, int col0, int cend, bool lower,
-                                               int wr, int wc, int lane, const d4_t (&acc)[2][2]) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int r = row0 + wr * 32 + i * 16 + (lane >> 4) + 4 * g;
-        const int c = col0 + wc * 32 + j * 16 + (lane & 15);
-        if (r <= n && c < cend && (!lower || c <= r)) S[(int64_t)r * n + c] = acc[i][j][g];
-      }
-}
-
-__device__ __forceinline__ bool chol_acc_nonzero(const d4_t (&acc)[2][2]) {
-  bool nz = false;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) nz |= acc[i][j][g] != 0.0;
-  return nz;
-}
-
-// flag of P_(I, q), I > q: 1 when that tile of the factor is entirely zero
-__device__ __forceinline__ int chol_zero(const int32_t* __restrict__ zflags, int np, int q, int I) {
-  return zflags[(int64_t)q * (np + 1) + (I - q - 1)];
-}
-
-// tile of S at (row0, col0) -> dst [64][64], rows past n as zeros
-__global__ __launch_bounds__(256) void k_chol_tile_copy(const double* __restrict__ S, int n, int row0, int col0,
-                                                        double* __restrict__ dst) {
-  double v[NB * NB / 256];
-  chol_tile_regs(S, n, row0, col0, true, threadIdx.x, v);
-#pragma unroll
-  for (int it = 0; it < NB * NB / 256; ++it) dst[threadIdx.x + 256 * it] = v[it];
-}
-
-// q_lo: first panel the bulk has not applied to block column k; c_lo < c_hi: panels the bulk workgroups
-// of this launch apply (none when equal)
-// look: the bulk runs one panel behind (lag 1) and the workgroup of row tile k + 2 looks ahead - besides
-// its own tile (k+2, k) it brings tile (k+2, k+1) and the diagonal block (k+2, k+2) up to date through
-// panel k (it forms P_(k+1,k) a second time for that, from the copy of tile (k+1, k) its predecessor
-// left in tws[k & 1]: the chain overwrites the tile in S during this launch), so that the chain of the
-// next launch finds both of its tiles complete and is left with two products and the factorisation.
-// The bulk skips those two tiles.  tws: two 64 x 64 tiles.
-__global__ __launch_bounds__(256, 2) void k_chol_step(double* __restrict__ S, int n, int k, int np, int q_lo, int c_lo,
-                                                   int c_hi, int n_row_tiles, int look, int32_t* __restrict__ zflags,
-                                                   double* __restrict__ invL_all, double* __restrict__ tws,
-                                                   int32_t* __restrict__ info) {
-  __shared__ double Pi[NB * LDT];
-  __shared__ double Pj[NB * LDT];
-  __shared__ int any_nz;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int k0 = k * NB;
-  const int nb = (n - k0) < NB ? (n - k0) : NB;
-  const int base = k0 + nb;
-  const bool has_next = base < n;
-  const bool aligned = nb == NB;  // (otherwise: last panel, the only row below is the right-hand side's)
-  const double* invL = invL_all + (int64_t)k * NB * NB;
-  int32_t* zf_k = zflags + (int64_t)k * (np + 1);
-  int b = blockIdx.x;
-  if (has_next && b == 0) {
-    // ---- the chain ----
-    const int I = k + 1, row0 = base;
-    const int nbn = (n - base) < NB ? (n - base) : NB;
-    d4_t a1[2][2], aD[2][2];
-    chol_acc_load(S, n, row0, k0, k0 + nb, false, wr, wc, lane, a1);
-    chol_acc_load(S, n, row0, row0, n, true, wr, wc, lane, aD);
-    for (int q = look ? k : q_lo; q < k; ++q) {
-      if (chol_zero(zflags, np, q, I)) continue;
-      const bool zk = chol_zero(zflags, np, q, k) != 0;
-      double vi[NB * NB / 256], vj[NB * NB / 256];
-      chol_tile_regs(S, n, row0, q * NB, true, t, vi);
-      if (!zk) chol_tile_regs(S, n, k0, q * NB, false, t, vj);
-      __syncthreads();
-      chol_regs_lds(vi, Pi, t);
-      if (!zk) chol_regs_lds(vj, Pj, t);
-      __syncthreads();
-      if (!zk) mfma_quadrant(Pi, Pj, wr, wc, lane, true, a1);
-      // (rows of the diagonal block's second operand past the matrix edge - the right-hand-side row -
-      // only meet columns that are never stored)
-      mfma_quadrant(Pi, Pi, wr, wc, lane, true, aD);
-    }
-    if (t == 0) any_nz = 0;
-    __syncthreads();
-    if (__any(chol_acc_nonzero(a1)) && lane == 0) any_nz = 1;
-    {
-      double vl[NB * NB / 256];
-#pragma unroll
-      for (int it = 0; it < NB * NB / 256; ++it) {
-        const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
-        vl[it] = (c <= r) ? invL[idx] : 0.0;
-      }
-      chol_acc_lds(a1, Pj, wr, wc, lane);
-      chol_regs_lds(vl, Pi, t);
-    }
-    __syncthreads();
-    const bool nz = any_nz != 0;
-    if (t == 0) zf_k[0] = nz ? 0 : 1;
-    if (nz) {
-      d4_t p[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) p[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
-      mfma_quadrant(Pj, Pi, wr, wc, lane, false, p);
-      chol_acc_store(S, n, row0, k0, k0 + nb, false, wr, wc, lane, p);
-      __syncthreads();
-      chol_acc_lds(p, Pi, wr, wc, lane);
-      __syncthreads();
-      mfma_quadrant(Pi, Pi, wr, wc, lane, true, aD);
-    } else if (q_lo < k && !look) {
-      chol_acc_store(S, n, row0, k0, k0 + nb, false, wr, wc, lane, a1);  // cancelled exactly: store the zeros
-    }
-    __syncthreads();
-    // park the diagonal block in LDS (identity padding past the matrix edge) and factor it; the rows of
-    // this tile under a partial last block (the right-hand-side row) go back to memory
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int r = wr * 32 + i * 16 + (lane >> 4) + 4 * g;
-          const int c = wc * 32 + j * 16 + (lane & 15);
-          double v = (r == c) ? 1.0 : 0.0;
-          if (r < nbn && c < nbn) v = (c <= r) ? aD[i][j][g] : 0.0;
-          Pi[r * LDT + c] = v;
-          if (r >= nbn && base + r <= n && c < nbn) S[(int64_t)(base + r) * n + base + c] = aD[i][j][g];
-        }
-    diag_core(Pi, Pj, S, n, base, nbn, invL_all + (int64_t)(k + 1) * NB * NB, info);
-    return;
-  }
-  if (has_next) --b;
-  const bool look_role = look && has_next && base + NB < n;
-  if (look_role && b == 0) {
-    // ---- row tile k + 2, looking ahead ----
-    const int row0 = base + NB, I = k + 2;
-    d4_t a[2][2], e[2][2], d[2][2];
-    chol_acc_load(S, n, row0, k0, k0 + nb, false, wr, wc, lane, a);
-    chol_acc_load(S, n, row0, base, n, false, wr, wc, lane, e);
-    chol_acc_load(S, n, row0, row0, n, true, wr, wc, lane, d);
-    if (k >= 1 && !chol_zero(zflags, np, k - 1, I)) {
-      const int q = k - 1;
-      const bool zk = chol_zero(zflags, np, q, k) != 0, z1 = chol_zero(zflags, np, q, k + 1) != 0;
-      double vi[NB * NB / 256], vj[NB * NB / 256], vm[NB * NB / 256];
-      chol_tile_regs(S, n, row0, q * NB, true, t, vi);
-      if (!zk) chol_tile_regs(S, n, k0, q * NB, false, t, vj);
-      if (!z1) chol_tile_regs(S, n, base, q * NB, false, t, vm);
-      chol_regs_lds(vi, Pi, t);
-      if (!zk) chol_regs_lds(vj, Pj, t);
-      __syncthreads();
-      if (!zk) mfma_quadrant(Pi, Pj, wr, wc, lane, true, a);
-      mfma_quadrant(Pi, Pi, wr, wc, lane, true, d);
-      __syncthreads();
-      if (!z1) {
-        chol_regs_lds(vm, Pj, t);
-        __syncthreads();
-        mfma_quadrant(Pi, Pj, wr, wc, lane, true, e);
-      }
-    }
-    if (t == 0) any_nz = 0;
-    __syncthreads();
-    if (__any(chol_acc_nonzero(a)) && lane == 0) any_nz = 1;
-    double vt[NB * NB / 256];
-    {
-      const double* tsrc = tws + (int64_t)(k & 1) * NB * NB;
-      double vl[NB * NB / 256];
-#pragma unroll
-      for (int it = 0; it < NB * NB / 256; ++it) {
-        const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
-        vl[it] = (c <= r) ? invL[idx] : 0.0;
-        vt[it] = tsrc[idx];
-      }
-      chol_acc_lds(a, Pj, wr, wc, lane);
-      chol_regs_lds(vl, Pi, t);
-    }
-    __syncthreads();
-    const bool nz = any_nz != 0;
-    if (t == 0) zf_k[1] = nz ? 0 : 1;
-    d4_t p[2][2], p1[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) p[i][j] = p1[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
-    if (nz) {
-      mfma_quadrant(Pj, Pi, wr, wc, lane, false, p);
-      chol_acc_store(S, n, row0, k0, k0 + nb, false, wr, wc, lane, p);
-    } else if (k >= 1) {
-      chol_acc_store(S, n, row0, k0, k0 + nb, false, wr, wc, lane, a);  // cancelled exactly: store the zeros
-    }
-    if (nz) {
-      __syncthreads();
-      chol_regs_lds(vt, Pj, t);
-      __syncthreads();
-      mfma_quadrant(Pj, Pi, wr, wc, lane, false, p1);  // P_(k+1,k)
-      __syncthreads();
-      chol_acc_lds(p, Pi, wr, wc, lane);
-      chol_acc_lds(p1, Pj, wr, wc, lane);
-      __syncthreads();
-      mfma_quadrant(Pi, Pj, wr, wc, lane, true, e);
-      mfma_quadrant(Pi, Pi, wr, wc, lane, true, d);
-    }
-    chol_acc_store(S, n, row0, base, n, false, wr, wc, lane, e);
-    chol_acc_store(S, n, row0, row0, n, true, wr, wc, lane, d);
-    {
-      // the copy the next launch's look-ahead reads while its chain overwrites the tile in S
-      double* tdst = tws + (int64_t)((k + 1) & 1) * NB * NB;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            tdst[(wr * 32 + i * 16 + (lane >> 4) + 4 * g) * NB + wc * 32 + j * 16 + (lane & 15)] = e[i][j][g];
-    }
-    return;
-  }
-  if (look_role) --b;
-  const int first_row_tile = (has_next ? 1 : 0) + (look_role ? 1 : 0);
-  const int n_solve = n_row_tiles - first_row_tile;
-  if (b < n_solve) {
-    // ---- row tile of block column k: missing panels, then the solve ----
-    const int ti = first_row_tile + b;
-    const int row0 = base + ti * NB, I = k + 1 + ti;
-    d4_t a1[2][2];
-    chol_acc_load(S, n, row0, k0, k0 + nb, false, wr, wc, lane, a1);
-    if (aligned) {
-      for (int q = q_lo; q < k; ++q) {
-        if (chol_zero(zflags, np, q, I) | chol_zero(zflags, np, q, k)) continue;
-        double vi[NB * NB / 256], vj[NB * NB / 256];
-        chol_tile_regs(S, n, row0, q * NB, true, t, vi);
-        chol_tile_regs(S, n, k0, q * NB, false, t, vj);
-        __syncthreads();
-        chol_regs_lds(vi, Pi, t);
-        chol_regs_lds(vj, Pj, t);
-        __syncthreads();
-        mfma_quadrant(Pi, Pj, wr, wc, lane, true, a1);
-      }
-    }
-    if (t == 0) any_nz = 0;
-    __syncthreads();
-    if (__any(chol_acc_nonzero(a1)) && lane == 0) any_nz = 1;
-    {
-      double vl[NB * NB / 256];
-#pragma unroll
-      for (int it = 0; it < NB * NB / 256; ++it) {
-        const int idx = t + 256 * it, r = idx / NB, c = idx % NB;
-        vl[it] = (c <= r) ? invL[idx] : 0.0;
-      }
-      chol_acc_lds(a1, Pj, wr, wc, lane);
-      chol_regs_lds(vl, Pi, t);
-    }
-    __syncthreads();
-    const bool nz = any_nz != 0;
-    if (t == 0) zf_k[ti] = nz ? 0 : 1;
-    if (!nz) {
-      // (a tile that the missing panels cancelled exactly: what memory holds is stale)
-      if (aligned && q_lo < k) chol_acc_store(S, n, row0, k0, k0 + nb, false, wr, wc, lane, a1);
-      return;
-    }
-    d4_t p[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) p[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
-    mfma_quadrant(Pj, Pi, wr, wc, lane, false, p);
-    chol_acc_store(S, n, row0, k0, k0 + nb, false, wr, wc, lane, p);
-    return;
-  }
-  b -= n_solve;
-  // ---- bulk: tile (ti, tj) of the trailing matrix, lower triangle without its first tile ----
-  if (c_hi <= c_lo) return;
-  const int lin = b + (look_role ? 3 : 1);
-  int ti = (int)((sqrt(8.0 * lin + 1.0) - 1.0) * 0.5);
-  while ((int64_t)(ti + 1) * (ti + 2) / 2 <= lin) ++ti;
-  while ((int64_t)ti * (ti + 1) / 2 > lin) --ti;
-  const int tj = lin - ti * (ti + 1) / 2;
-  if (ti >= n_row_tiles) return;
-  const int row0 = base + ti * NB, col0 = base + tj * NB;
-  if (col0 >= n) return;
-  const int I = k + 1 + ti, J = k + 1 + tj;
-  bool any = false;
-  for (int q = c_lo; q < c_hi; ++q) any |= (chol_zero(zflags, np, q, I) | chol_zero(zflags, np, q, J)) == 0;
-  if (!any) return;
-  d4_t acc[2][2];
-  chol_acc_load(S, n, row0, col0, n, ti == tj, wr, wc, lane, acc);
-  for (int q = c_lo; q < c_hi; ++q) {
-    if (chol_zero(zflags, np, q, I) | chol_zero(zflags, np, q, J)) continue;
-    double vi[NB * NB / 256], vj[NB * NB / 256];
-    chol_tile_regs(S, n, row0, q * NB, true, t, vi);
-    chol_tile_regs(S, n, col0, q * NB, false, t, vj);
-    __syncthreads();
-    chol_regs_lds(vi, Pi, t);
-    chol_regs_lds(vj, Pj, t);
-    __syncthreads();
-    mfma_quadrant(Pi, Pj, wr, wc, lane, true, acc);
-  }
-  chol_acc_store(S, n, row0, col0, n, ti == tj, wr, wc, lane, acc);
-}
-
-// backward substitution step for panel k0: x_k = invL_kk^T y_k (recomputed by every workgroup), then
-// workgroup w removes L[k0.., cols of tile w]^T x_k from y.  Workgroup 0 also stores x_k.
-__global__ __launch_bounds__(256) void k_chol_back(const double* __restrict__ S, int n, int k0, int nb,
-                                                   const double* __restrict__ invL, double* __restrict__ y,
-                                                   double* __restrict__ x, const int32_t* __restrict__ zflags,
-                                                   int np) {
-  __shared__ double xk[NB];
+// Backward substitution L^T x = y, a group of up to four panels kTop, kTop - 1, ... in one launch: every workgroup walks the
+// group's own chain (x of the panel, its contribution to the next panel's right-hand side, ...) - a few
+// 64 x 64 matrix-vector products, done by all workgroups alike - and then takes the group's contribution
+// off its own 64 columns of y.  A quarter of the launches of the panel-by-panel form; the factor's tiles
+// of the workgroup's own columns are fetched before the chain starts.
+constexpr int kBackGroup = 4;
+__global__ __launch_bounds__(256) void k_chol_back_group(const double* __restrict__ S, int n, int kTop, int m,
+                                                         const double* __restrict__ invL_all, double* __restrict__ y,
+                                                         double* __restrict__ x, const int32_t* __restrict__ zflags,
+                                                         int np) {
+  __shared__ double xs[kBackGroup][NB];
+  __shared__ double ys[NB];
   __shared__ double part[4][NB];
   const int t = threadIdx.x;
   const int col = t & 63, rq = t >> 6;
-  // this workgroup's columns are panel j = blockIdx.x; rows k0.. are row tile (k - j - 1) below it
-  bool skip = k0 == 0;
-  if (k0 > 0) skip = zflags[(int64_t)blockIdx.x * (np + 1) + (k0 / NB - blockIdx.x - 1)] != 0;
-  if (skip && blockIdx.x > 0) return;  // workgroup 0 always runs: it stores x_k
-  // the factor's tile is fetched before x_k is known: its addresses do not depend on it
-  const int c = blockIdx.x * NB + col;
-  double lv[NB / 4];
+  const int j = blockIdx.x;
+  const bool has_cols = j <= kTop - m;  // a column tile below the group (workgroup 0 always runs: it stores x)
+  // Everything the chain reads from memory is requested here, before the first sum: none of the addresses
+  // depends on x (few workgroups, one per CU: registers are not what limits this kernel).
+  //   lv: own columns - rows of the group's panels, column j * 64 + col
+  //   iv: column `col` of each panel's (lower-triangular) inverse, rows rq, rq + 4, ...
+  //   gv: the group's own tiles - rows of panel kTop - sp, column `col` of panel kTop - s, sp < s
+  //   yv: the panels' entries of y
+  double lv[kBackGroup][NB / 4], iv[kBackGroup][NB / 4], gv[kBackGroup * (kBackGroup - 1) / 2][NB / 4], yv[kBackGroup];
 #pragma unroll
-  for (int i = 0; i < NB / 4; ++i) {
-    const int r = rq + 4 * i;
-    lv[i] = (!skip && c < k0 && r < nb) ? S[(int64_t)(k0 + r) * n + c] : 0.0;
-  }
-  {
-    // rows r = rq, rq+4, ... of column `col` of the (zero-padded, lower-triangular) inverse
-    double s = 0.0;
+  for (int s = 0; s < kBackGroup; ++s) {
+    const int kg = kTop - s, k0 = kg * NB;
+    const bool in = s < m;
+    const int nb = in ? ((n - k0) < NB ? (n - k0) : NB) : 0;
+    const bool on = has_cols && in && zflags[(int64_t)j * (np + 1) + (kg - j - 1)] == 0;
+    const double* invL = invL_all + (int64_t)(in ? kg : 0) * NB * NB;
 #pragma unroll
     for (int i = 0; i < NB / 4; ++i) {
       const int r = rq + 4 * i;
-      // only the lower triangle of the inverse is stored (rows past nb hold identity padding)
-      const bool on = r < nb && col <= r;
-      const double iv = on ? invL[r * NB + col] : 0.0;
-      const double yv = on ? y[k0 + r] : 0.0;
-      s += iv * yv;
+      lv[s][i] = (on && r < nb) ? S[(int64_t)(k0 + r) * n + j * NB + col] : 0.0;
+      iv[s][i] = (r < nb && col <= r) ? invL[r * NB + col] : 0.0;
     }
-    part[rq][col] = s;
-  }
-  __syncthreads();
-  if (t < NB) {
-    const double s = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
-    xk[t] = s;
-    if (blockIdx.x == 0 && t < nb) x[k0 + t] = s;
-  }
-  __syncthreads();
-  if (skip) return;
-  double s = 0.0;
+    yv[s] = (t < nb) ? y[k0 + t] : 0.0;
 #pragma unroll
-  for (int i = 0; i < NB / 4; ++i) s += lv[i] * xk[rq + 4 * i];
+    for (int sp = 0; sp < s; ++sp) {
+      const int kp = kTop - sp, k0p = kp * NB;
+      const int nbp = (n - k0p) < NB ? (n - k0p) : NB;
+      const bool gon = in && zflags[(int64_t)kg * (np + 1) + (kp - kg - 1)] == 0;
+#pragma unroll
+      for (int i = 0; i < NB / 4; ++i) {
+        const int r = rq + 4 * i;
+        gv[s * (s - 1) / 2 + sp][i] = (gon && r < nbp && col < nb) ? S[(int64_t)(k0p + r) * n + k0 + col] : 0.0;
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < kBackGroup; ++s) {
+    if (s < m) {
+      const int k0 = (kTop - s) * NB;
+      const int nb = (n - k0) < NB ? (n - k0) : NB;
+      // right-hand side of this panel: y minus what the panels above it in the group contribute
+      double acc = 0.0;
+#pragma unroll
+      for (int sp = 0; sp < s; ++sp)
+#pragma unroll
+        for (int i = 0; i < NB / 4; ++i) acc += gv[s * (s - 1) / 2 + sp][i] * xs[sp][rq + 4 * i];
+      part[rq][col] = acc;
+      __syncthreads();
+      if (t < NB) ys[t] = yv[s] - ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t]));
+      __syncthreads();
+      double s2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < NB / 4; ++i) s2 += iv[s][i] * ys[rq + 4 * i];
+      part[rq][col] = s2;
+      __syncthreads();
+      if (t < NB) {
+        const double v = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+        xs[s][t] = v;
+        if (j == 0 && t < nb) x[k0 + t] = v;
+      }
+      __syncthreads();
+    }
+  }
+  if (!has_cols) return;
+  double a = 0.0;
+#pragma unroll
+  for (int s = 0; s < kBackGroup; ++s)
+    if (s < m) {
+#pragma unroll
+      for (int i = 0; i < NB / 4; ++i) a += lv[s][i] * xs[s][rq + 4 * i];
+    }
+  part[rq][col] = a;
   __syncthreads();
-  part[rq][col] = s;
-  __syncthreads();
-  if (t < NB && c < k0) y[c] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+  if (t < NB) y[j * NB + t] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
 }
 
 // ---- band path -------------------------------------------------------------------------------
@@ -1782,62 +1306,45 @@ int launch_solve_reduced(double* S, int n, int half_bandwidth, double* da, void*
     const int Cw = wide_band_tiles(n, half_bandwidth);
     if (Cw > 0 && Cw <= wide_band_limit()) return launch_solve_wide_band(S, n, Cw, da, ws, info, st);
   }
-  static const int step_mode = [] {
-    const char* e = getenv("SFM_BA_CHOL_STEP");
-    return e ? atoi(e) : 1;
-  }();
+  // diagnostic switches: SFM_BA_CHOL_LAG=<panels per pass of the trailing matrix>, SFM_BA_CHOL_LOOK=0 (no look-ahead)
   static const int lag_env = [] {
     const char* e = getenv("SFM_BA_CHOL_LAG");
     return e ? atoi(e) : 0;
   }();
-  if (step_mode) {
-    // one launch per panel (k_chol_step); the trailing matrix takes two panels per pass once it no
-    // longer fits the last-level cache
-    const int lag = lag_env > 0 ? lag_env : (n >= 6000 ? 2 : 1);
-    const int look = lag == 1 && step_mode != 2;
-    double* tws = reinterpret_cast<double*>(zflags + ((((int64_t)np * (np + 2) + 64) + 1) & ~int64_t(1)));
-    if (look && 2 * NB < n) hipLaunchKernelGGL(k_chol_tile_copy, dim3(1), dim3(256), 0, st, S, n, NB, 0, tws);
-    hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, st, S, n, 0, n < NB ? n : NB, invL, info);
-    for (int k = 0; k < np; ++k) {
-      const int k0 = k * NB;
-      const int nb = (n - k0) < NB ? (n - k0) : NB;
-      const int base = k0 + nb;
-      const bool has_next = base < n;
-      const int ntile = (n + 1 - base + NB - 1) / NB;  // row tiles below the panel, the right-hand side's included
-      const int q_lo = k > 0 ? lag * ((k - 1) / lag) : 0;
-      const bool bulk = has_next && k >= lag && k % lag == 0;
-      const int64_t nt = (int64_t)ntile * (ntile + 1) / 2;
-      const bool look_role = look && has_next && base + NB < n;
-      const int64_t grid = ntile + (bulk ? nt - 1 - (look_role ? 2 : 0) : 0);
-      if (grid <= 0) continue;
-      hipLaunchKernelGGL(k_chol_step, dim3((unsigned)grid), dim3(256), 0, st, S, n, k, np, q_lo, bulk ? k - lag : 0,
-                         bulk ? k : 0, ntile, look, zflags, invL, tws, info);
-    }
-  } else
+  static const int look_env = [] {
+    const char* e = getenv("SFM_BA_CHOL_LOOK");
+    return e ? atoi(e) : 1;
+  }();
+  // one launch per panel (ba_chol_step.inc).  While the trailing matrix is large its tiles take two panels per
+  // pass (half the traffic); below ~9 000 unknowns the chain of diagonal factorisations is what bounds the
+  // factorisation, and the look-ahead that shortens it needs one panel per pass (measured crossover).
+  const int lag = lag_env > 0 ? lag_env : (n >= 9000 ? 2 : 1);
+  const int look = lag == 1 && look_env != 0;
+  double* side = reinterpret_cast<double*>(zflags + ((((int64_t)np * (np + 2) + 64) + 1) & ~int64_t(1)));
+  if (look && 2 * NB < n) hipLaunchKernelGGL(k_chol_tile_copy, dim3(2), dim3(256), 0, st, S, n, NB, 0, 2 * NB, NB, side);
+  hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, st, S, n, 0, n < NB ? n : NB, invL, info);
   for (int k = 0; k < np; ++k) {
     const int k0 = k * NB;
     const int nb = (n - k0) < NB ? (n - k0) : NB;
-    // the diagonal block of panel k > 0 was factored by the update of panel k-1
-    if (k == 0) hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, st, S, n, k0, nb, invL, info);
-    const int rows_below = n + 1 - (k0 + nb);  // includes the right-hand-side row
-    const int ntile = (rows_below + NB - 1) / NB;
-    if (ntile > 0) {
-      hipLaunchKernelGGL(k_chol_panel, dim3(ntile), dim3(256), 0, st, S, n, k0, nb, invL + (int64_t)k * NB * NB,
-                         zflags + (int64_t)k * (np + 1));
-      if (k0 + nb < n) {
-        const int64_t nt = (int64_t)ntile * (ntile + 1) / 2;
-        hipLaunchKernelGGL(k_chol_update, dim3((unsigned)nt), dim3(256), 0, st, S, n, k0, nb, ntile,
-                           zflags + (int64_t)k * (np + 1), invL + (int64_t)(k + 1) * NB * NB, info);
-      }
+    const int base = k0 + nb;
+    const bool has_next = base < n;
+    const int ntile = (n + 1 - base + NB - 1) / NB;  // row tiles below the panel, the right-hand side's included
+    int64_t bulk = 0;
+    if (has_next && k >= 1) {
+      const int64_t nT = n / 128 - base / 128 + 1;  // 128-row tiles from the one that holds row `base` to row n's
+      bulk = nT * (nT + 1) / 2;
     }
+    int64_t grid = ntile + bulk;
+    if (grid <= 0) continue;
+    if (grid > 256) grid += 2;  // two workgroups without a role, see k_chol_step
+    hipLaunchKernelGGL(k_chol_step, dim3((unsigned)grid), dim3(256), 0, st, S, n, k, np, lag, look, ntile, zflags, invL, side,
+                       info);
   }
   hipLaunchKernelGGL(k_copy_row, dim3((n + 255) / 256), dim3(256), 0, st, S + (int64_t)n * n, y, n);
-  for (int k = np - 1; k >= 0; --k) {
-    const int k0 = k * NB;
-    const int nb = (n - k0) < NB ? (n - k0) : NB;
-    const int nwg = k0 > 0 ? (k0 + NB - 1) / NB : 1;
-    hipLaunchKernelGGL(k_chol_back, dim3(nwg), dim3(256), 0, st, S, n, k0, nb, invL + (int64_t)k * NB * NB, y, da,
-                       zflags, np);
+  for (int k = np - 1; k >= 0; k -= kBackGroup) {
+    const int m = k + 1 < kBackGroup ? k + 1 : kBackGroup;
+    const int nwg = k - m + 1 > 0 ? k - m + 1 : 1;
+    hipLaunchKernelGGL(k_chol_back_group, dim3(nwg), dim3(256), 0, st, S, n, k, m, invL, y, da, zflags, np);
   }
   err = hipGetLastError();
   if (err != hipSuccess) {

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["ba_kernels.hip", "ba_fused.hip", "ba_cholesky.hip", "ba_triangulate.hip", "ba_pnp.hip", "ba_plan.cpp", "ba_plan_device.hip", "ba_capi.cpp", "ba_profile.cpp"]
-HEADERS = ["ba_common.h", "ba_rows.h", "ba_bcr_wide.inc", "ba_fused_step_a.inc", "ba_fused_step_b.inc", "ba_fused_flush.inc",
+HEADERS = ["ba_common.h", "ba_rows.h", "ba_bcr_wide.inc", "ba_chol_step.inc", "ba_fused_step_a.inc", "ba_fused_step_b.inc", "ba_fused_flush.inc",
            os.path.join("..", "..", "include", "sfm_ba.h")]
 # SFM_BA_VARIANT=<name>: a diagnostic build beside the library (libsfm_ba_<name>.so, objects of its own),
 # which _lib.py loads when the same variable is set

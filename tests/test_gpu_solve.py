@@ -104,3 +104,45 @@ def test_not_positive_definite_is_reported(n, hb, bad_row):
     S[bad_row, bad_row] = -1.0
     _, info, _ = _solve(S, e, hb if hb is not None else 0, banded_entry=hb is not None)
     assert info != 0
+
+
+# dense systems through the general path (one launch per panel): one panel, two, the look-ahead with and without
+# a partial last panel, n a multiple of 64 (the right-hand side in a row tile of its own), the size of the
+# benchmark's dense reduced system, and one above the size from which the trailing matrix takes two panels per pass
+@pytest.mark.parametrize("n", [40, 65, 130, 200, 640, 1000, 3500, 3520, 9100])
+def test_dense_general_path(n):
+    """Against an LU solve of the same system (GPU, fp64) at 1e-11; the factor left in S reproduces the
+    matrix (sizes up to 1000); the workspace is scratch - filled with NaN, then with huge numbers, the result
+    must not change by a bit; no pivot flag."""
+    import torch
+    import sfm_amd  # noqa: F401
+    from sfm_amd import _lib
+
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(n)
+    G = torch.randn((n, n + 16), dtype=torch.float64, device="cuda", generator=g)
+    S0 = G @ G.T / n + 0.5 * torch.eye(n, dtype=torch.float64, device="cuda")
+    e = torch.randn((n,), dtype=torch.float64, device="cuda", generator=g)
+    x_ref = torch.linalg.solve(S0, e)
+    buf = torch.empty((n + 1, n), dtype=torch.float64, device="cuda")
+    da = torch.empty((n,), dtype=torch.float64, device="cuda")
+    ws = torch.empty((int(lib.sfm_ba_cholesky_workspace_bytes(n)) // 8 + 8,), dtype=torch.float64, device="cuda")
+    info = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    p = _lib.ptr
+    first = None
+    for fill in (float("nan"), 1e300, 0.0):
+        buf[:n].copy_(S0)
+        buf[n].copy_(e)
+        ws.fill_(fill)
+        da.fill_(float("nan"))
+        _lib.check(lib.sfm_ba_solve_reduced(p(buf), n, p(da), p(ws), p(info), None))
+        torch.cuda.synchronize()
+        assert int(info.item()) == 0
+        if first is None:
+            first = da.clone()
+            assert float((da - x_ref).norm() / x_ref.norm()) <= 1e-11
+            if n <= 1000:
+                L = torch.tril(buf[:n])
+                assert float((L @ L.T - S0).abs().max() / S0.abs().max()) <= 1e-13
+        else:
+            assert bool((da == first).all().item())
