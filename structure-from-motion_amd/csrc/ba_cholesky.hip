@@ -147,7 +147,7 @@ __device__ __forceinline__ void diag_core(double* __restrict__ L, double* __rest
   const int li = lane & 15, lk = lane >> 4;
 
   // tile (bi, bc) -= L[rows of bi, block column kc] L[rows of bc, block column kc]^T
-  auto upd_tile = [&](int bi, int bc, int kc) {
+  auto upd_tile = [&](int bi, int bc, int kc, bool dup = false) {
     d4_t c4;
     double av[4], bv[4];
 #pragma unroll
@@ -161,6 +161,10 @@ __device__ __forceinline__ void diag_core(double* __restrict__ L, double* __rest
     for (int q = 0; q < 4; ++q) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], c4, 0, 0, 0);
 #pragma unroll
     for (int g = 0; g < 4; ++g) L[(bi * SB + lk + 4 * g) * LDT + bc * SB + li] = c4[g];
+    if (dup) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) X[(bi * SB + lk + 4 * g) * LDT + bc * SB + li] = c4[g];
+    }
   };
   // dst tile = -X_(bi,bi) sum_{q = q_lo}^{q_hi - 1} L[rows of bi, 4q..4q+3] X[4q..4q+3, cols of bj].  The
   // inner sum leaves the accumulator in exactly the lane layout the second product wants for its
@@ -205,6 +209,14 @@ __device__ __forceinline__ void diag_core(double* __restrict__ L, double* __rest
   };
 
   __syncthreads();
+  // Wave 1 factors a copy of the diagonal 16 x 16 block of every phase, and wave 0 stores the factored
+  // block column over the original inside the same phase: wave 1 must not read it from there (nothing
+  // orders its loads before wave 0's stores - seen going wrong about once in 20 000 calls when the waves
+  // of a workgroup drift apart).  It reads the block from X's diagonal block of the phase instead, which
+  // holds nothing until wave 1 itself writes the block's inverse there: the first one is copied here, the
+  // later ones are left there by the update that completes them (upd_tile with dup).
+  if (t < SB * SB) X[(t / SB) * LDT + t % SB] = L[(t / SB) * LDT + t % SB];
+  __syncthreads();
   STAMP(0);
   for (int kk = 0; kk < NS; ++kk) {
     const int o = kk * SB;
@@ -215,7 +227,7 @@ __device__ __forceinline__ void diag_core(double* __restrict__ L, double* __rest
       double a[SB];
 #pragma unroll
       for (int c = 0; c < SB; ++c) {
-        a[c] = from_l ? L[row * LDT + o + c] : 0.0;
+        a[c] = from_l ? (wave == 0 ? L : X)[row * LDT + o + c] : 0.0;
         if (wave == 1 && lane - SB == c) a[c] = 1.0;
       }
       STAMP(20 + kk);
@@ -258,7 +270,7 @@ __device__ __forceinline__ void diag_core(double* __restrict__ L, double* __rest
     STAMP(2 + 4 * kk);
     __syncthreads();  // block column kk of L and X_kk are final
     STAMP(3 + 4 * kk);
-    if (kk < NS - 1 && wave < NS - 1 - kk) upd_tile(kk + 1 + wave, kk + 1, kk);
+    if (kk < NS - 1 && wave < NS - 1 - kk) upd_tile(kk + 1 + wave, kk + 1, kk, wave == 0);
     STAMP(4 + 4 * kk);
     if (kk < NS - 1) __syncthreads();
   }
@@ -1306,22 +1318,26 @@ int launch_solve_reduced(double* S, int n, int half_bandwidth, double* da, void*
     const int Cw = wide_band_tiles(n, half_bandwidth);
     if (Cw > 0 && Cw <= wide_band_limit()) return launch_solve_wide_band(S, n, Cw, da, ws, info, st);
   }
-  // diagnostic switches: SFM_BA_CHOL_LAG=<panels per pass of the trailing matrix>, SFM_BA_CHOL_LOOK=0 (no look-ahead)
-  static const int lag_env = [] {
-    const char* e = getenv("SFM_BA_CHOL_LAG");
-    return e ? atoi(e) : 0;
+  // diagnostic switches: SFM_BA_CHOL_SWITCH=<unknowns left from which every tile of the trailing matrix is
+  // updated in every launch> (0: never), SFM_BA_CHOL_LOOK=0 (no look-ahead)
+  static const int switch_env = [] {
+    const char* e = getenv("SFM_BA_CHOL_SWITCH");
+    return e ? atoi(e) : 9000;
   }();
   static const int look_env = [] {
     const char* e = getenv("SFM_BA_CHOL_LOOK");
     return e ? atoi(e) : 1;
   }();
-  // one launch per panel (ba_chol_step.inc).  While the trailing matrix is large its tiles take two panels per
-  // pass (half the traffic); below ~9 000 unknowns the chain of diagonal factorisations is what bounds the
-  // factorisation, and the look-ahead that shortens it needs one panel per pass (measured crossover).
-  const int lag = lag_env > 0 ? lag_env : (n >= 9000 ? 2 : 1);
-  const int look = lag == 1 && look_env != 0;
+  // one launch per panel (ba_chol_step.inc).  While more than ~9 000 unknowns are left the tiles of the
+  // trailing matrix take two panels per pass, every second launch (half the traffic); below that the chain
+  // of diagonal factorisations is what bounds a launch, every tile is updated in every launch and the
+  // look-ahead shortens the chain (measured crossover).
+  int ks = switch_env > 0 ? (n - switch_env + NB - 1) / NB : np + 1;
+  if (ks < 2) ks = 0;
+  const int look = look_env != 0;
   double* side = reinterpret_cast<double*>(zflags + ((((int64_t)np * (np + 2) + 64) + 1) & ~int64_t(1)));
-  if (look && 2 * NB < n) hipLaunchKernelGGL(k_chol_tile_copy, dim3(2), dim3(256), 0, st, S, n, NB, 0, 2 * NB, NB, side);
+  if (look && ks == 0 && 2 * NB < n)
+    hipLaunchKernelGGL(k_chol_tile_copy, dim3(2), dim3(256), 0, st, S, n, NB, 0, 2 * NB, NB, side);
   hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, st, S, n, 0, n < NB ? n : NB, invL, info);
   for (int k = 0; k < np; ++k) {
     const int k0 = k * NB;
@@ -1337,7 +1353,7 @@ int launch_solve_reduced(double* S, int n, int half_bandwidth, double* da, void*
     int64_t grid = ntile + bulk;
     if (grid <= 0) continue;
     if (grid > 256) grid += 2;  // two workgroups without a role, see k_chol_step
-    hipLaunchKernelGGL(k_chol_step, dim3((unsigned)grid), dim3(256), 0, st, S, n, k, np, lag, look, ntile, zflags, invL, side,
+    hipLaunchKernelGGL(k_chol_step, dim3((unsigned)grid), dim3(256), 0, st, S, n, k, np, ks, look, ntile, zflags, invL, side,
                        info);
   }
   hipLaunchKernelGGL(k_copy_row, dim3((n + 255) / 256), dim3(256), 0, st, S + (int64_t)n * n, y, n);
