@@ -6,6 +6,7 @@ RUN=$1; RT=$2
 cd "$(dirname "$0")/.."
 cp "$(ls -t gpurun_out/prof_${RUN}/*/*kernel_stats.csv | head -1)" profiles/${RT}_c4_banded_kernel_stats.csv
 cp gpurun_out/${RUN}_prof_summary.txt profiles/${RT}_c4_banded_kernel_summary.txt
+[ -f gpurun_out/${RUN}_uniform_prof_summary.txt ] && cp gpurun_out/${RUN}_uniform_prof_summary.txt profiles/${RT}_c4_uniform_kernel_summary.txt
 for n in c4_banded c4_tracks c4_uniform venice_banded; do
   cp gpurun_out/${RUN}_${n}_pmc_fetch.txt profiles/${RT}_${n}_pmc_fetch_size.txt
   cp gpurun_out/${RUN}_${n}_pmc_write.txt profiles/${RT}_${n}_pmc_write_size.txt

@@ -11,6 +11,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd $R
 bash scripts/gpu_prof.sh ${TAG} --no-extra-records > gpurun_out/${TAG}_prof_summary.txt || exit 2
+# the same for uniform visibility (camera-pair assembly from the state, dense factorisation)
+bash scripts/gpu_prof.sh ${TAG}u --visibility uniform --no-extra-records --no-cpu-baseline > gpurun_out/${TAG}_uniform_prof_summary.txt || exit 2
 pmc_pair() {  # <name> <traffic key> <bench args...>
   local NAME=$1 KEY=$2; shift; shift
   bash scripts/gpu_pmc.sh ${TAG}_${NAME}_fetch FETCH_SIZE $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-records "$@" > gpurun_out/${TAG}_${NAME}_pmc_fetch.txt || return 3
